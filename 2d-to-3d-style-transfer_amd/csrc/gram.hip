@@ -1,0 +1,252 @@
+// gram.hip -- Gram matrix forward/backward on the gfx950 fp32 matrix pipe.
+//   forward : G_b = F_b F_b^T, F_b = feat[b] viewed (C, HW)        (style_transfer.py:31-35)
+//   backward: dF_b (+)= coef * D_b F_b, D_b = G_b - S_b symmetric   (autograd of losses.py:36-39)
+// One batched, split-K GEMM kernel (v_mfma_f32_32x32x2_f32, 4 waves as 2x2, k-major LDS
+// tiles so both operands are lane-contiguous ds_read_b32) serves both:
+//   forward  = "NT": A = F (M=C, K=HW contiguous), B = F^T given as [N][K]; K split over
+//              workgroups (HW is up to 2^20 while the output is only CxC); only tiles on or
+//              above the diagonal are computed; each split writes its own slab and an ordered
+//              reduce kernel sums the slabs (bitwise reproducible, no float atomics).
+//   backward = "NN": A = D (M=C, K=C), B = F as [K][N=HW].
+// Arithmetic intensity is 32 flop/B per 128x128 tile (A/B tiles re-read through L2), at the
+// fp32 ridge for C = 64 where F (the largest activation) is streamed exactly once.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int KCH = 32;
+
+struct GemmArgs {
+    const float *A; const float *B; float *C;
+    int M, N, K;
+    int lda, ldb, ldc;
+    size_t sA, sB, sC;      // batch strides (elements)
+    size_t sSplit;          // split-K slab stride of C (elements)
+    int nsplit, kper;       // K range per split
+    int tiles_m, tiles_n, tri;
+    float coef; int accumulate;
+};
+
+// load 4 consecutive elements p[0..3] along a contiguous axis, zero past `remain`
+__device__ __forceinline__ float4 load4(const float *p, int remain, bool aligned) {
+    if (remain >= 4 && aligned) return *reinterpret_cast<const float4 *>(p);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (remain > 0) v.x = p[0];
+    if (remain > 1) v.y = p[1];
+    if (remain > 2) v.z = p[2];
+    if (remain > 3) v.w = p[3];
+    return v;
+}
+
+// MT/NT: 32x32 MFMA tiles per wave along M/N.  BMODE 0: B is [N][K]; 1: B is [K][N].
+template <int MT, int NT, int BMODE>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
+    constexpr int TM = 2 * MT * 32, TN = 2 * NT * 32;
+    constexpr int LA = TM + 1;
+    constexpr int LB = (BMODE == 0) ? TN + 1 : TN;
+    constexpr int A4 = TM * KCH / 4 / 256;      // float4 loads per thread for the A tile
+    constexpr int B4 = TN * KCH / 4 / 256;
+    __shared__ __attribute__((aligned(16))) float As[KCH * LA];
+    __shared__ __attribute__((aligned(16))) float Bs[KCH * LB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    int ti, tj;
+    if (g.tri) {   // upper-triangular tile pairs (ti <= tj)
+        int t = blockIdx.x; ti = 0;
+        while (t >= g.tiles_n - ti) { t -= g.tiles_n - ti; ++ti; }
+        tj = ti + t;
+    } else {
+        ti = blockIdx.x / g.tiles_n; tj = blockIdx.x % g.tiles_n;
+    }
+    const int split = blockIdx.y, b = blockIdx.z;
+    const int m0 = ti * TM, n0 = tj * TN;
+    const int kbeg = split * g.kper, kend = min(g.K, kbeg + g.kper);
+
+    const float *Ab = g.A + b * g.sA;
+    const float *Bb = g.B + b * g.sB;
+    const bool a_al = ((g.lda & 3) == 0) && ((((uintptr_t)Ab) & 15) == 0);
+    const bool b_al = ((g.ldb & 3) == 0) && ((((uintptr_t)Bb) & 15) == 0);
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int q = 0; q < NT; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.f;
+
+    float4 av[A4], bv[B4];
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < A4; ++i) {       // A tile: TM rows x 32 k, 8 float4 per row
+            const int e = tid + i * 256, row = e >> 3, kq = (e & 7) * 4;
+            const int gm = m0 + row, gk = k0 + kq;
+            av[i] = (gm < g.M) ? load4(Ab + (size_t)gm * g.lda + gk, kend - gk, a_al && ((gk & 3) == 0))
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < B4; ++i) {
+            const int e = tid + i * 256;
+            if (BMODE == 0) {                // [N][K]: TN rows x 32 k
+                const int row = e >> 3, kq = (e & 7) * 4;
+                const int gn = n0 + row, gk = k0 + kq;
+                bv[i] = (gn < g.N) ? load4(Bb + (size_t)gn * g.ldb + gk, kend - gk, b_al && ((gk & 3) == 0))
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {                         // [K][N]: 32 k rows x TN cols
+                const int kr = e / (TN / 4), nq = (e - kr * (TN / 4)) * 4;
+                const int gk = k0 + kr, gn = n0 + nq;
+                bv[i] = (gk < kend) ? load4(Bb + (size_t)gk * g.ldb + gn, g.N - gn, b_al && ((gn & 3) == 0))
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int i = 0; i < A4; ++i) {
+            const int e = tid + i * 256, row = e >> 3, kq = (e & 7) * 4;
+            As[(kq + 0) * LA + row] = av[i].x; As[(kq + 1) * LA + row] = av[i].y;
+            As[(kq + 2) * LA + row] = av[i].z; As[(kq + 3) * LA + row] = av[i].w;
+        }
+#pragma unroll
+        for (int i = 0; i < B4; ++i) {
+            const int e = tid + i * 256;
+            if (BMODE == 0) {
+                const int row = e >> 3, kq = (e & 7) * 4;
+                Bs[(kq + 0) * LB + row] = bv[i].x; Bs[(kq + 1) * LB + row] = bv[i].y;
+                Bs[(kq + 2) * LB + row] = bv[i].z; Bs[(kq + 3) * LB + row] = bv[i].w;
+            } else {
+                const int kr = e / (TN / 4), nq = (e - kr * (TN / 4)) * 4;
+                *reinterpret_cast<float4 *>(&Bs[kr * LB + nq]) = bv[i];
+            }
+        }
+    };
+
+    if (kbeg < kend) load_tiles(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += KCH) {
+        __syncthreads();                     // previous chunk's reads done
+        store_tiles();
+        __syncthreads();
+        if (k0 + KCH < kend) load_tiles(k0 + KCH);   // in flight during the MFMAs below
+        const float *pa = As + lhi * LA + wm * (MT * 32) + l31;
+        const float *pb = Bs + lhi * LB + wn * (NT * 32) + l31;
+#pragma unroll
+        for (int kk = 0; kk < KCH / 2; ++kk) {
+            float a[MT], bb[NT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) a[m] = pa[(kk * 2) * LA + m * 32];
+#pragma unroll
+            for (int q = 0; q < NT; ++q) bb[q] = pb[(kk * 2) * LB + q * 32];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int q = 0; q < NT; ++q)
+                    acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bb[q], acc[m][q], 0, 0, 0);
+        }
+    }
+
+    float *Cb = g.C + b * g.sC + split * g.sSplit;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int gm = m0 + wm * (MT * 32) + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            if (gm >= g.M) continue;
+#pragma unroll
+            for (int q = 0; q < NT; ++q) {
+                const int gn = n0 + wn * (NT * 32) + q * 32 + l31;
+                if (gn < g.N) {
+                    float *dst = Cb + (size_t)gm * g.ldc + gn;
+                    const float v = g.coef * acc[m][q][r];
+                    *dst = g.accumulate ? (*dst + v) : v;
+                }
+            }
+        }
+}
+
+// G[b][i][j] = sum over splits (in order) of the slab element; tiles below the diagonal are
+// read transposed from the mirrored tile.
+__global__ __launch_bounds__(256) void gram_reduce_kernel(const float *__restrict__ slab, int nsplit, int C, int TM,
+                                                          size_t sSplit, size_t sB, float *__restrict__ gram) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t CC = (size_t)C * C;
+    if (i >= CC) return;
+    const int b = blockIdx.y;
+    int r = i / C, c = i % C;
+    if (r / TM > c / TM) { const int t = r; r = c; c = t; }
+    const float *p = slab + b * sB + (size_t)r * C + c;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += p[k * sSplit];
+    gram[b * CC + i] = s;
+}
+
+int gram_split(int C, int HW, int *kper) {
+    int ns = (HW + 2047) / 2048;
+    if (C >= 256 && ns < 4 && HW >= 4 * 256) ns = 4;
+    if (ns > 256) ns = 256;
+    if (ns < 1) ns = 1;
+    int kp = (HW + ns - 1) / ns;
+    kp = (kp + KCH - 1) / KCH * KCH;
+    ns = (HW + kp - 1) / kp;
+    *kper = kp;
+    return ns;
+}
+
+}  // namespace
+
+extern "C" size_t st3d_gram_workspace_bytes(int B, int C, int HW) {
+    int kper;
+    const int ns = gram_split(C, HW, &kper);
+    return (size_t)B * ns * C * C * sizeof(float);
+}
+
+extern "C" int st3d_gram_fwd(const float *feat, int B, int C, int HW, void *workspace, size_t workspace_bytes, float *gram,
+                             st3d_stream_t stream) {
+    ST3D_CHECK_ARG(feat && workspace && gram);
+    ST3D_CHECK_ARG(B > 0 && C > 0 && HW > 0);
+    ST3D_CHECK_ARG(workspace_bytes >= st3d_gram_workspace_bytes(B, C, HW));
+    hipStream_t s = st3d::as_stream(stream);
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.nsplit = gram_split(C, HW, &g.kper);
+    g.A = feat; g.B = feat; g.C = reinterpret_cast<float *>(workspace);
+    g.M = C; g.N = C; g.K = HW; g.lda = HW; g.ldb = HW; g.ldc = C;
+    g.sA = g.sB = (size_t)C * HW;
+    g.sSplit = (size_t)C * C; g.sC = g.sSplit * g.nsplit;
+    g.tri = 1; g.coef = 1.f; g.accumulate = 0;
+    const int TM = (C % 128 == 0) ? 128 : 64;
+    g.tiles_m = g.tiles_n = st3d::cdiv(C, TM);
+    dim3 grid(g.tiles_n * (g.tiles_n + 1) / 2, g.nsplit, B);
+    if (TM == 128) gemm_kernel<2, 2, 0><<<grid, 256, 0, s>>>(g);
+    else gemm_kernel<1, 1, 0><<<grid, 256, 0, s>>>(g);
+    ST3D_LAUNCH_CHECK();
+    gram_reduce_kernel<<<dim3(st3d::cdiv((long)C * C, 256), B), 256, 0, s>>>(g.C, g.nsplit, C, TM, g.sSplit, g.sC, gram);
+    ST3D_LAUNCH_CHECK();
+    return ST3D_OK;
+}
+
+extern "C" int st3d_gram_bwd(const float *D, const float *feat, int B, int C, int HW, float coef, int accumulate,
+                             float *gfeat, st3d_stream_t stream) {
+    ST3D_CHECK_ARG(D && feat && gfeat);
+    ST3D_CHECK_ARG(B > 0 && C > 0 && HW > 0);
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = D; g.B = feat; g.C = gfeat;
+    g.M = C; g.N = HW; g.K = C; g.lda = C; g.ldb = HW; g.ldc = HW;
+    g.sA = (size_t)C * C; g.sB = g.sC = (size_t)C * HW;
+    g.nsplit = 1; g.kper = (C + KCH - 1) / KCH * KCH; g.sSplit = 0;
+    g.tri = 0; g.coef = coef; g.accumulate = accumulate;
+    hipStream_t s = st3d::as_stream(stream);
+    if (C % 128 == 0) {
+        g.tiles_m = C / 128; g.tiles_n = st3d::cdiv(HW, 128);
+        gemm_kernel<2, 2, 1><<<dim3(g.tiles_m * g.tiles_n, 1, B), 256, 0, s>>>(g);
+    } else {
+        g.tiles_m = st3d::cdiv(C, 64); g.tiles_n = st3d::cdiv(HW, 128);
+        gemm_kernel<1, 2, 1><<<dim3(g.tiles_m * g.tiles_n, 1, B), 256, 0, s>>>(g);
+    }
+    ST3D_LAUNCH_CHECK();
+    return ST3D_OK;
+}

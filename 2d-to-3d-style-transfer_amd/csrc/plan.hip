@@ -1,0 +1,423 @@
+// plan.hip -- host-side engine of libst3d: error reporting, the frozen VGG-19 weight store
+// (utils.py:48-52) and the fused perceptual-loss plan (losses.py:12-44 /
+// style_transfer.py:59-83): forward to conv5_1 keeping the post-ReLU taps, Gram + content
+// losses, and the hand-scheduled backward to d loss / d image.  The graph is static, so the
+// backward is a fixed launch sequence over preallocated workspaces (no autograd tape, no
+// allocation per step); what the reference recomputes every call but does not depend on the
+// optimised parameters (content features, style Grams: losses.py:18-25) is set once through
+// st3d_plan_set_content / st3d_plan_set_style.
+#include <stdarg.h>
+
+#include <vector>
+
+#include "common.h"
+
+namespace st3d {
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+}  // namespace st3d
+
+extern "C" int st3d_version(void) { return 100; }
+extern "C" const char *st3d_last_error(void) { return st3d::g_err; }
+
+extern "C" int st3d_device_info(int device, int *cu_count, size_t *hbm_bytes, char *name, int name_len) {
+    hipDeviceProp_t p;
+    ST3D_HIP(hipGetDeviceProperties(&p, device));
+    if (cu_count) *cu_count = p.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = p.totalGlobalMem;
+    if (name && name_len > 0) {
+        snprintf(name, name_len, "%s (%s)", p.name, p.gcnArchName);
+    }
+    return ST3D_OK;
+}
+
+namespace {
+
+// torchvision vgg19().features layout: module index -> kind
+constexpr int kModules = 37;
+const int kConvIdx[16] = {0, 2, 5, 7, 10, 12, 14, 16, 19, 21, 23, 25, 28, 30, 32, 34};
+const int kConvCin[16] = {3, 64, 64, 128, 128, 256, 256, 256, 256, 512, 512, 512, 512, 512, 512, 512};
+const int kConvCout[16] = {64, 64, 128, 128, 256, 256, 256, 256, 512, 512, 512, 512, 512, 512, 512, 512};
+const int kPoolIdx[5] = {4, 9, 18, 27, 36};
+// style taps (style_transfer.py:12-19 minus conv4_2) and the content tap
+const int kStyleTap[5] = {0, 5, 10, 19, 28};
+constexpr int kContentTap = 21;
+
+int conv_slot(int module_idx) {
+    for (int i = 0; i < 16; ++i)
+        if (kConvIdx[i] == module_idx) return i;
+    return -1;
+}
+int pool_slot(int module_idx) {
+    for (int i = 0; i < 5; ++i)
+        if (kPoolIdx[i] == module_idx) return i;
+    return -1;
+}
+
+}  // namespace
+
+struct st3d_vgg {
+    float *wf[16];
+    float *wd[16];
+    float *bias[16];
+    bool set[16];
+};
+
+extern "C" int st3d_vgg_create(st3d_vgg **out) {
+    ST3D_CHECK_ARG(out);
+    st3d_vgg *v = new st3d_vgg();
+    memset(v, 0, sizeof(*v));
+    for (int i = 0; i < 16; ++i) {
+        const size_t n = st3d_conv3x3_packed_floats(kConvCout[i], kConvCin[i]);
+        if (hipMalloc(&v->wf[i], n * sizeof(float)) != hipSuccess || hipMalloc(&v->wd[i], n * sizeof(float)) != hipSuccess ||
+            hipMalloc(&v->bias[i], kConvCout[i] * sizeof(float)) != hipSuccess) {
+            st3d::set_error("st3d_vgg_create: hipMalloc failed");
+            st3d_vgg_destroy(v);
+            return ST3D_E_NOMEM;
+        }
+    }
+    *out = v;
+    return ST3D_OK;
+}
+
+extern "C" int st3d_vgg_set_conv(st3d_vgg *vgg, int module_idx, const float *w, const float *b, st3d_stream_t stream) {
+    ST3D_CHECK_ARG(vgg && w && b);
+    const int s = conv_slot(module_idx);
+    ST3D_CHECK_ARG(s >= 0);
+    ST3D_TRY(st3d_conv3x3_pack(w, kConvCout[s], kConvCin[s], vgg->wf[s], vgg->wd[s], stream));
+    ST3D_HIP(hipMemcpyAsync(vgg->bias[s], b, kConvCout[s] * sizeof(float), hipMemcpyDeviceToDevice, st3d::as_stream(stream)));
+    vgg->set[s] = true;
+    return ST3D_OK;
+}
+
+extern "C" int st3d_vgg_destroy(st3d_vgg *vgg) {
+    if (!vgg) return ST3D_OK;
+    for (int i = 0; i < 16; ++i) {
+        if (vgg->wf[i]) (void)hipFree(vgg->wf[i]);
+        if (vgg->wd[i]) (void)hipFree(vgg->wd[i]);
+        if (vgg->bias[i]) (void)hipFree(vgg->bias[i]);
+    }
+    delete vgg;
+    return ST3D_OK;
+}
+
+struct st3d_plan {
+    st3d_vgg *vgg;
+    int B, S;
+    // per module: output activation (conv: post-ReLU; relu: alias of its conv; pool: pooled)
+    float *act[kModules];
+    int C[kModules], H[kModules], W[kModules];
+    uint8_t *pidx[5];
+    float *gbuf[2];
+    size_t gbuf_floats;
+    // targets
+    float *content_target;   // (B, 512, S/8, S/8)
+    float *style_gram[5];     // (B or 1, C, C)
+    int style_batch;
+    bool have_content, have_style;
+    // per-step scratch
+    float *gram[5], *D[5];
+    void *gram_ws;
+    size_t gram_ws_bytes;
+    float *partials;
+    size_t bytes;
+    int last_n;
+    // profiling
+    bool prof;
+    struct Ev { int fam; hipEvent_t a, b; };
+    std::vector<Ev> evs;
+    std::vector<hipEvent_t> pool;
+    float fam_ms[6];
+    int fam_n[6];
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(st3d_plan *p, T **ptr, size_t count) {
+    const size_t bytes = count * sizeof(T);
+    if (hipMalloc(reinterpret_cast<void **>(ptr), bytes) != hipSuccess) {
+        st3d::set_error("st3d_plan_create: hipMalloc(%zu bytes) failed", bytes);
+        return ST3D_E_NOMEM;
+    }
+    p->bytes += bytes;
+    return ST3D_OK;
+}
+
+struct Scope {   // HIP-event bracket around one kernel family (only when profiling is on)
+    st3d_plan *p; int fam; hipStream_t s; hipEvent_t a, b; bool on;
+    Scope(st3d_plan *p_, int fam_, hipStream_t s_) : p(p_), fam(fam_), s(s_), on(p_->prof) {
+        if (!on) return;
+        auto get = [&]() {
+            hipEvent_t e;
+            if (!p->pool.empty()) { e = p->pool.back(); p->pool.pop_back(); } else { (void)hipEventCreate(&e); }
+            return e;
+        };
+        a = get(); b = get();
+        (void)hipEventRecord(a, s);
+    }
+    ~Scope() {
+        if (!on) return;
+        (void)hipEventRecord(b, s);
+        p->evs.push_back({fam, a, b});
+    }
+};
+
+enum { F_CONV_FWD = 0, F_CONV_DGRAD = 1, F_POOL = 2, F_GRAM_FWD = 3, F_GRAM_BWD = 4, F_ELEM = 5 };
+
+__global__ void combine_loss_kernel(float *loss, float sw, float cw) { loss[0] = cw * loss[1] + sw * loss[2]; }
+
+int forward(st3d_plan *p, const float *imgs, int n, int upto, hipStream_t s) {
+    const float *x = imgs;
+    int Cin = 3, H = p->S, W = p->S;
+    for (int m = 0; m <= upto; ++m) {
+        const int cs = conv_slot(m), ps = pool_slot(m);
+        if (cs >= 0) {
+            if (!p->vgg->set[cs]) {
+                st3d::set_error("st3d_plan_forward: weights of module %d were never set", m);
+                return ST3D_E_STATE;
+            }
+            Scope sc(p, F_CONV_FWD, s);
+            ST3D_TRY(st3d_conv3x3_fwd(x, p->vgg->wf[cs], p->vgg->bias[cs], p->act[m], n, Cin, kConvCout[cs], H, W, 1, s));
+            x = p->act[m];
+            Cin = kConvCout[cs];
+        } else if (ps >= 0) {
+            Scope sc(p, F_POOL, s);
+            ST3D_TRY(st3d_maxpool2x2_fwd(x, p->act[m], p->pidx[ps], n, Cin, H, W, s));
+            x = p->act[m];
+            H /= 2; W /= 2;
+        }   // ReLU modules are fused into their conv
+    }
+    p->last_n = n;
+    return ST3D_OK;
+}
+
+}  // namespace
+
+extern "C" int st3d_plan_create(st3d_plan **out, st3d_vgg *vgg, int B, int S) {
+    ST3D_CHECK_ARG(out && vgg);
+    ST3D_CHECK_ARG(B > 0 && S >= 32 && (S % 32) == 0);
+    st3d_plan *p = new st3d_plan();
+    p->vgg = vgg; p->B = B; p->S = S; p->bytes = 0;
+    for (int m = 0; m < kModules; ++m) { p->act[m] = nullptr; p->C[m] = p->H[m] = p->W[m] = 0; }
+    for (int i = 0; i < 5; ++i) { p->pidx[i] = nullptr; p->style_gram[i] = p->gram[i] = p->D[i] = nullptr; }
+    p->gbuf[0] = p->gbuf[1] = nullptr; p->content_target = nullptr; p->gram_ws = nullptr; p->partials = nullptr;
+    p->have_content = p->have_style = false; p->style_batch = 0; p->last_n = 0; p->prof = false;
+    memset(p->fam_ms, 0, sizeof(p->fam_ms)); memset(p->fam_n, 0, sizeof(p->fam_n));
+    int rc = ST3D_OK;
+    int C = 3, H = S, W = S;
+    size_t gmax = 0, wsmax = 0;
+    for (int m = 0; m < kModules && rc == ST3D_OK; ++m) {
+        const int cs = conv_slot(m), ps = pool_slot(m);
+        if (cs >= 0) {
+            C = kConvCout[cs];
+            rc = dev_alloc(p, &p->act[m], (size_t)B * C * H * W);
+            if ((size_t)B * C * H * W > gmax) gmax = (size_t)B * C * H * W;
+        } else if (ps >= 0) {
+            H /= 2; W /= 2;
+            rc = dev_alloc(p, &p->act[m], (size_t)B * C * H * W);
+            if (rc == ST3D_OK) rc = dev_alloc(p, &p->pidx[ps], (size_t)B * C * H * W);
+        } else {
+            p->act[m] = p->act[m - 1];   // in-place ReLU: the tap tensor IS the post-ReLU output
+        }
+        p->C[m] = C; p->H[m] = H; p->W[m] = W;
+    }
+    p->gbuf_floats = gmax;
+    for (int i = 0; i < 2 && rc == ST3D_OK; ++i) rc = dev_alloc(p, &p->gbuf[i], gmax);
+    if (rc == ST3D_OK) rc = dev_alloc(p, &p->content_target, (size_t)B * p->C[kContentTap] * p->H[kContentTap] * p->W[kContentTap]);
+    for (int i = 0; i < 5 && rc == ST3D_OK; ++i) {
+        const int m = kStyleTap[i];
+        const size_t cc = (size_t)B * p->C[m] * p->C[m];
+        rc = dev_alloc(p, &p->style_gram[i], cc);
+        if (rc == ST3D_OK) rc = dev_alloc(p, &p->gram[i], cc);
+        if (rc == ST3D_OK) rc = dev_alloc(p, &p->D[i], cc);
+        const size_t ws = st3d_gram_workspace_bytes(B, p->C[m], p->H[m] * p->W[m]);
+        if (ws > wsmax) wsmax = ws;
+    }
+    p->gram_ws_bytes = wsmax;
+    if (rc == ST3D_OK) { float *t = nullptr; rc = dev_alloc(p, &t, wsmax / sizeof(float)); p->gram_ws = t; }
+    if (rc == ST3D_OK) rc = dev_alloc(p, &p->partials, (size_t)st3d_reduce_partials());
+    if (rc != ST3D_OK) { st3d_plan_destroy(p); return rc; }
+    *out = p;
+    return ST3D_OK;
+}
+
+extern "C" int st3d_plan_destroy(st3d_plan *p) {
+    if (!p) return ST3D_OK;
+    for (int m = 0; m < kModules; ++m)
+        if (p->act[m] && (m == 0 || p->act[m] != p->act[m - 1])) (void)hipFree(p->act[m]);
+    for (int i = 0; i < 5; ++i) {
+        if (p->pidx[i]) (void)hipFree(p->pidx[i]);
+        if (p->style_gram[i]) (void)hipFree(p->style_gram[i]);
+        if (p->gram[i]) (void)hipFree(p->gram[i]);
+        if (p->D[i]) (void)hipFree(p->D[i]);
+    }
+    for (int i = 0; i < 2; ++i)
+        if (p->gbuf[i]) (void)hipFree(p->gbuf[i]);
+    if (p->content_target) (void)hipFree(p->content_target);
+    if (p->gram_ws) (void)hipFree(p->gram_ws);
+    if (p->partials) (void)hipFree(p->partials);
+    for (auto &e : p->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto &e : p->pool) (void)hipEventDestroy(e);
+    delete p;
+    return ST3D_OK;
+}
+
+extern "C" size_t st3d_plan_bytes(const st3d_plan *p) { return p ? p->bytes : 0; }
+
+extern "C" int st3d_plan_forward(st3d_plan *p, const float *imgs, int n, int upto_module, st3d_stream_t stream) {
+    ST3D_CHECK_ARG(p && imgs);
+    ST3D_CHECK_ARG(n > 0 && n <= p->B && upto_module >= 0 && upto_module < kModules);
+    return forward(p, imgs, n, upto_module, st3d::as_stream(stream));
+}
+
+extern "C" int st3d_plan_activation(st3d_plan *p, int module_idx, float **ptr, int *C, int *H, int *W) {
+    ST3D_CHECK_ARG(p && ptr && module_idx >= 0 && module_idx < kModules);
+    *ptr = p->act[module_idx];
+    if (C) *C = p->C[module_idx];
+    if (H) *H = p->H[module_idx];
+    if (W) *W = p->W[module_idx];
+    return ST3D_OK;
+}
+
+extern "C" int st3d_plan_set_content(st3d_plan *p, const float *content, int n, st3d_stream_t stream) {
+    ST3D_CHECK_ARG(p && content && n > 0 && n <= p->B);
+    hipStream_t s = st3d::as_stream(stream);
+    ST3D_TRY(forward(p, content, n, kContentTap, s));
+    const size_t cnt = (size_t)n * p->C[kContentTap] * p->H[kContentTap] * p->W[kContentTap];
+    ST3D_HIP(hipMemcpyAsync(p->content_target, p->act[kContentTap], cnt * sizeof(float), hipMemcpyDeviceToDevice, s));
+    p->have_content = true;
+    return ST3D_OK;
+}
+
+extern "C" int st3d_plan_set_style(st3d_plan *p, const float *style, int style_batch, int n, st3d_stream_t stream) {
+    ST3D_CHECK_ARG(p && style && n > 0 && n <= p->B && (style_batch == 1 || style_batch == n));
+    hipStream_t s = st3d::as_stream(stream);
+    ST3D_TRY(forward(p, style, style_batch, 28, s));
+    for (int i = 0; i < 5; ++i) {
+        const int m = kStyleTap[i];
+        Scope sc(p, F_GRAM_FWD, s);
+        ST3D_TRY(st3d_gram_fwd(p->act[m], style_batch, p->C[m], p->H[m] * p->W[m], p->gram_ws, p->gram_ws_bytes,
+                               p->style_gram[i], s));
+    }
+    p->style_batch = style_batch;
+    p->have_style = true;
+    return ST3D_OK;
+}
+
+extern "C" int st3d_plan_loss(st3d_plan *p, const float *current, int n, int batch_denom, float style_weight,
+                              float content_weight, float *loss_out, float *grad_current, st3d_stream_t stream) {
+    ST3D_CHECK_ARG(p && current && loss_out);
+    ST3D_CHECK_ARG(n > 0 && n <= p->B && batch_denom >= n);
+    if (!p->have_content || !p->have_style) {
+        st3d::set_error("st3d_plan_loss: content/style targets not set");
+        return ST3D_E_STATE;
+    }
+    ST3D_CHECK_ARG(p->style_batch == 1 || p->style_batch == n);
+    hipStream_t s = st3d::as_stream(stream);
+    ST3D_TRY(forward(p, current, n, 28, s));
+    ST3D_HIP(hipMemsetAsync(loss_out, 0, 3 * sizeof(float), s));
+
+    const double bd = (double)batch_denom;
+    // content loss: mean over (B,C,H,W) of (F - Ft)^2            (losses.py:31)
+    const int mc = kContentTap;
+    const size_t chw = (size_t)p->C[mc] * p->H[mc] * p->W[mc];
+    {
+        Scope sc(p, F_ELEM, s);
+        ST3D_TRY(st3d_sqdiff_sum(p->act[mc], p->content_target, (size_t)n * chw, (size_t)n * chw,
+                                 (float)(1.0 / (bd * (double)chw)), nullptr, p->partials, loss_out + 1, s));
+    }
+    // style loss: sum_l mean over (B,C,C) of (G - S)^2 / (C^2 H^2) (losses.py:34-39)
+    float style_coef[5];
+    for (int i = 0; i < 5; ++i) {
+        const int m = kStyleTap[i];
+        const double C = p->C[m], Hh = p->H[m];
+        {
+            Scope sc(p, F_GRAM_FWD, s);
+            ST3D_TRY(st3d_gram_fwd(p->act[m], n, p->C[m], p->H[m] * p->W[m], p->gram_ws, p->gram_ws_bytes, p->gram[i], s));
+        }
+        const size_t cc = (size_t)p->C[m] * p->C[m];
+        const double norm = 1.0 / (bd * C * C) / (C * C * Hh * Hh);
+        {
+            Scope sc(p, F_ELEM, s);
+            ST3D_TRY(st3d_sqdiff_sum(p->gram[i], p->style_gram[i], (size_t)n * cc, p->style_batch == 1 ? cc : (size_t)n * cc,
+                                     (float)norm, p->D[i], p->partials, loss_out + 2, s));
+        }
+        style_coef[i] = (float)(4.0 * (double)style_weight * norm);   // d/dF = 2*(dG + dG^T)/2 ... = 4 w norm D F
+    }
+    combine_loss_kernel<<<1, 1, 0, s>>>(loss_out, style_weight, content_weight);
+    ST3D_LAUNCH_CHECK();
+    if (!grad_current) return ST3D_OK;
+
+    // ---- backward: gradient w.r.t. the post-ReLU output of each conv, top down
+    float *g = p->gbuf[0], *gn = p->gbuf[1];
+    bool have_g = false, g_is_pooled = false;
+    int pool_of_g = -1;
+    for (int cs = 12; cs >= 0; --cs) {          // conv slots 12 (module 28) .. 0
+        const int m = kConvIdx[cs];
+        const int C = p->C[m], H = p->H[m], W = p->W[m];
+        int st = -1;
+        for (int i = 0; i < 5; ++i)
+            if (kStyleTap[i] == m) st = i;
+        if (st >= 0) {
+            Scope sc(p, F_GRAM_BWD, s);
+            ST3D_TRY(st3d_gram_bwd(p->D[st], p->act[m], n, C, H * W, style_coef[st], have_g ? 1 : 0, g, s));
+            have_g = true;
+        }
+        if (m == kContentTap) {
+            Scope sc(p, F_ELEM, s);
+            ST3D_TRY(st3d_axpy_diff(p->act[m], p->content_target, (size_t)n * C * H * W,
+                                    (float)(2.0 * (double)content_weight / (bd * (double)chw)), have_g ? 1 : 0, g, s));
+            have_g = true;
+        }
+        if (!have_g) continue;
+        float *dst = (cs == 0) ? grad_current : gn;
+        {
+            Scope sc(p, F_CONV_DGRAD, s);
+            if (g_is_pooled) {
+                ST3D_TRY(st3d_conv3x3_dgrad_unpool(g, p->pidx[pool_of_g], p->act[kPoolIdx[pool_of_g]], p->vgg->wd[cs], dst, n,
+                                                   kConvCin[cs], kConvCout[cs], H, W, s));
+            } else {
+                ST3D_TRY(st3d_conv3x3_dgrad(g, p->act[m], p->vgg->wd[cs], dst, n, kConvCin[cs], kConvCout[cs], H, W, s));
+            }
+        }
+        // dst is the gradient w.r.t. this conv's input: either the previous conv's post-ReLU
+        // output or a pool output (then the next dgrad fuses the unpool)
+        g_is_pooled = (m > 0) && pool_slot(m - 1) >= 0;
+        pool_of_g = g_is_pooled ? pool_slot(m - 1) : -1;
+        float *t = g; g = gn; gn = t;
+    }
+    return ST3D_OK;
+}
+
+extern "C" int st3d_plan_profile(st3d_plan *p, int enable) {
+    ST3D_CHECK_ARG(p);
+    p->prof = enable != 0;
+    return ST3D_OK;
+}
+
+extern "C" int st3d_plan_profile_read(st3d_plan *p, float *ms_out, int *launches_out) {
+    ST3D_CHECK_ARG(p);
+    for (auto &e : p->evs) {
+        ST3D_HIP(hipEventSynchronize(e.b));
+        float ms = 0.f;
+        ST3D_HIP(hipEventElapsedTime(&ms, e.a, e.b));
+        p->fam_ms[e.fam] += ms;
+        p->fam_n[e.fam] += 1;
+        p->pool.push_back(e.a);
+        p->pool.push_back(e.b);
+    }
+    p->evs.clear();
+    for (int i = 0; i < 6; ++i) {
+        if (ms_out) ms_out[i] = p->fam_ms[i];
+        if (launches_out) launches_out[i] = p->fam_n[i];
+        p->fam_ms[i] = 0.f;
+        p->fam_n[i] = 0;
+    }
+    return ST3D_OK;
+}

@@ -1,0 +1,214 @@
+// raster.hip -- hard rasteriser for gfx950 (K = 1 face per pixel, blur_radius = 0,
+// perspective-correct barycentrics): the device work behind utils.py:69
+// `renderer(meshes_world=..., cameras=camera)` -> PyTorch3D MeshRasterizer, configured at
+// first_approach.py:107 / second_approach.py:101.
+//
+// Layout / kernels (all B views of a batch in one launch each):
+//   project_verts_kernel   (B*V threads)   world -> (x_ndc, y_ndc, z_view)
+//   face_setup_kernel      (B*F threads)   gathers the 3 projected vertices of every face into a
+//                                          48-byte record (3 x float4) so the tile kernel streams
+//                                          faces with coalesced 16-B loads instead of 9 gathers
+//   raster_tile_kernel     one 256-thread workgroup per 16x16 pixel tile: the four waves sweep
+//                          the face list 256 faces at a time, bbox-test them against the tile
+//                          (wave ballots -> ordered compaction), stage the surviving faces'
+//                          records in LDS, then every lane (= pixel) walks the LDS list
+//                          (same-address broadcast reads, no bank conflicts).
+// HBM-bound by construction: algorithmic bytes per view = F*48 (records, re-read once per tile
+// from L2) + S*S*24 written.  Built with -ffp-contract=off so the arithmetic is the same
+// operation sequence as oracle/raster_ref.c (bit-comparable).
+#include "common.h"
+
+namespace {
+
+constexpr float kEps = 1e-8f;
+constexpr int TILE = 16;       // 16x16 pixels per workgroup
+constexpr int LIST_CAP = 512;  // faces staged in LDS per flush
+
+__device__ __forceinline__ float pix_to_ndc(int i, int S) { return -1.0f + (2.0f * (float)i + 1.0f) / (float)S; }
+
+__device__ __forceinline__ float edge_fn(float px, float py, float ax, float ay, float bx, float by) {
+    return (px - ax) * (by - ay) - (py - ay) * (bx - ax);
+}
+
+__device__ __forceinline__ float point_line_dist2(float px, float py, float ax, float ay, float bx, float by) {
+    const float bax = bx - ax, bay = by - ay;
+    const float l2 = bax * bax + bay * bay;
+    if (l2 <= kEps) {
+        const float dx = px - bx, dy = py - by;
+        return dx * dx + dy * dy;
+    }
+    float t = (bax * (px - ax) + bay * (py - ay)) / l2;
+    t = t < 0.f ? 0.f : (t > 1.f ? 1.f : t);
+    const float qx = ax + t * bax, qy = ay + t * bay;
+    const float dx = qx - px, dy = qy - py;
+    return dx * dx + dy * dy;
+}
+
+__global__ void project_verts_kernel(const float *__restrict__ verts, int V, const float *__restrict__ R,
+                                     const float *__restrict__ T, int B, float s, float *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * V) return;
+    const int b = i / V, v = i - b * V;
+    const float *r = R + 9 * b, *t = T + 3 * b;
+    const float x = verts[3 * v], y = verts[3 * v + 1], z = verts[3 * v + 2];
+    const float xv = x * r[0] + y * r[3] + z * r[6] + t[0];
+    const float yv = x * r[1] + y * r[4] + z * r[7] + t[1];
+    const float zv = x * r[2] + y * r[5] + z * r[8] + t[2];
+    out[3 * (size_t)i + 0] = (s * xv) / zv;
+    out[3 * (size_t)i + 1] = (s * yv) / zv;
+    out[3 * (size_t)i + 2] = zv;
+}
+
+// record: [x0 y0 z0 x1][y1 z1 x2 y2][z2 valid 0 0]
+__global__ void face_setup_kernel(const float *__restrict__ ndc, const int32_t *__restrict__ faces, int B, int V, int F,
+                                  float4 *__restrict__ rec) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * F) return;
+    const int b = i / F, f = i - b * F;
+    const float *vb = ndc + (size_t)b * V * 3;
+    const int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
+    const float x0 = vb[3 * i0], y0 = vb[3 * i0 + 1], z0 = vb[3 * i0 + 2];
+    const float x1 = vb[3 * i1], y1 = vb[3 * i1 + 1], z1 = vb[3 * i1 + 2];
+    const float x2 = vb[3 * i2], y2 = vb[3 * i2 + 1], z2 = vb[3 * i2 + 2];
+    const float zmax = fmaxf(z0, fmaxf(z1, z2));
+    const float area = edge_fn(x2, y2, x0, y0, x1, y1);
+    const bool valid = !(zmax < kEps) && !(area <= kEps && area >= -kEps);
+    rec[3 * (size_t)i + 0] = make_float4(x0, y0, z0, x1);
+    rec[3 * (size_t)i + 1] = make_float4(y1, z1, x2, y2);
+    rec[3 * (size_t)i + 2] = make_float4(z2, valid ? 1.f : 0.f, 0.f, 0.f);
+}
+
+struct Best {
+    int f;
+    float z, b0, b1, b2;
+};
+
+__device__ __forceinline__ void eval_face(int f, float x0, float y0, float z0, float x1, float y1, float z1, float x2,
+                                          float y2, float z2, float xf, float yf, Best &best) {
+    const float xmin = fminf(x0, fminf(x1, x2)), xmax = fmaxf(x0, fmaxf(x1, x2));
+    const float ymin = fminf(y0, fminf(y1, y2)), ymax = fmaxf(y0, fmaxf(y1, y2));
+    if (xf > xmax || xf < xmin || yf > ymax || yf < ymin) return;
+    const float area = edge_fn(x2, y2, x0, y0, x1, y1) + kEps;
+    const float w0 = edge_fn(xf, yf, x1, y1, x2, y2) / area;
+    const float w1 = edge_fn(xf, yf, x2, y2, x0, y0) / area;
+    const float w2 = edge_fn(xf, yf, x0, y0, x1, y1) / area;
+    const float t0 = w0 * z1 * z2;
+    const float t1 = z0 * w1 * z2;
+    const float t2 = z0 * z1 * w2;
+    const float den = fmaxf(t0 + t1 + t2, kEps);
+    const float b0 = t0 / den, b1 = t1 / den, b2 = t2 / den;
+    const float pz = b0 * z0 + b1 * z1 + b2 * z2;
+    if (pz < 0.f) return;
+    if (!((b0 > 0.f) && (b1 > 0.f) && (b2 > 0.f))) return;  // blur_radius == 0: only inside pixels survive
+    if (best.f < 0 || pz < best.z) {                          // list is in face order: ties keep the smaller index
+        best.f = f; best.z = pz; best.b0 = b0; best.b1 = b1; best.b2 = b2;
+    }
+}
+
+__global__ __launch_bounds__(256) void raster_tile_kernel(const float4 *__restrict__ rec, int F, int S,
+                                                          int32_t *__restrict__ pix_to_face, float *__restrict__ zbuf,
+                                                          float *__restrict__ bary, float *__restrict__ dists) {
+    __shared__ float s_face[LIST_CAP][9];
+    __shared__ int s_fidx[LIST_CAP];
+    __shared__ int s_wcnt[4];
+
+    const int b = blockIdx.z;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int px = blockIdx.x * TILE + (tid & (TILE - 1));
+    const int py = blockIdx.y * TILE + (tid >> 4);
+    const bool in_img = px < S && py < S;
+    const float xf = pix_to_ndc(S - 1 - px, S);
+    const float yf = pix_to_ndc(S - 1 - py, S);
+    // tile extent in NDC (pixel centres); +x / +y point left / up so the min pixel index is the max coord
+    const int px_hi = min(blockIdx.x * TILE + TILE - 1, S - 1), py_hi = min(blockIdx.y * TILE + TILE - 1, S - 1);
+    const float tx_max = pix_to_ndc(S - 1 - blockIdx.x * TILE, S), tx_min = pix_to_ndc(S - 1 - px_hi, S);
+    const float ty_max = pix_to_ndc(S - 1 - blockIdx.y * TILE, S), ty_min = pix_to_ndc(S - 1 - py_hi, S);
+
+    const float4 *rb = rec + (size_t)b * F * 3;
+    Best best;
+    best.f = -1; best.z = 0.f; best.b0 = best.b1 = best.b2 = 0.f;
+    int count = 0;
+
+    for (int base = 0; base < F; base += 256) {
+        const int f = base + tid;
+        bool hit = false;
+        float4 r0, r1, r2;
+        if (f < F) {
+            r0 = rb[3 * (size_t)f]; r1 = rb[3 * (size_t)f + 1]; r2 = rb[3 * (size_t)f + 2];
+            const float xmin = fminf(r0.x, fminf(r0.w, r1.z)), xmax = fmaxf(r0.x, fmaxf(r0.w, r1.z));
+            const float ymin = fminf(r0.y, fminf(r1.x, r1.w)), ymax = fmaxf(r0.y, fmaxf(r1.x, r1.w));
+            hit = (r2.y != 0.f) && !(tx_min > xmax || tx_max < xmin || ty_min > ymax || ty_max < ymin);
+        }
+        const unsigned long long m = __ballot(hit);
+        if (lane == 0) s_wcnt[wave] = __popcll(m);
+        __syncthreads();
+        int off = count;
+        for (int w = 0; w < wave; ++w) off += s_wcnt[w];
+        const int total = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+        if (hit) {
+            const int slot = off + __popcll(m & ((1ull << lane) - 1ull));
+            s_fidx[slot] = f;
+            s_face[slot][0] = r0.x; s_face[slot][1] = r0.y; s_face[slot][2] = r0.z;
+            s_face[slot][3] = r0.w; s_face[slot][4] = r1.x; s_face[slot][5] = r1.y;
+            s_face[slot][6] = r1.z; s_face[slot][7] = r1.w; s_face[slot][8] = r2.x;
+        }
+        count += total;
+        __syncthreads();
+        const bool last = base + 256 >= F;
+        if (count > LIST_CAP - 256 || last) {
+            for (int i = 0; i < count; ++i) {
+                eval_face(s_fidx[i], s_face[i][0], s_face[i][1], s_face[i][2], s_face[i][3], s_face[i][4], s_face[i][5],
+                          s_face[i][6], s_face[i][7], s_face[i][8], xf, yf, best);
+            }
+            count = 0;
+            __syncthreads();
+        }
+    }
+    if (!in_img) return;
+    const size_t p = ((size_t)b * S + py) * S + px;
+    if (best.f >= 0) {
+        const float4 r0 = rb[3 * (size_t)best.f], r1 = rb[3 * (size_t)best.f + 1];
+        const float d01 = point_line_dist2(xf, yf, r0.x, r0.y, r0.w, r1.x);
+        const float d12 = point_line_dist2(xf, yf, r0.w, r1.x, r1.z, r1.w);
+        const float d20 = point_line_dist2(xf, yf, r1.z, r1.w, r0.x, r0.y);
+        const float d = fminf(d01, fminf(d12, d20));
+        pix_to_face[p] = best.f; zbuf[p] = best.z; dists[p] = -d;
+        bary[3 * p] = best.b0; bary[3 * p + 1] = best.b1; bary[3 * p + 2] = best.b2;
+    } else {
+        pix_to_face[p] = -1; zbuf[p] = -1.f; dists[p] = -1.f;
+        bary[3 * p] = -1.f; bary[3 * p + 1] = -1.f; bary[3 * p + 2] = -1.f;
+    }
+}
+
+}  // namespace
+
+extern "C" int st3d_project_verts(const float *verts, int V, const float *R, const float *T, int B,
+                                  float inv_tan_half_fov, float *verts_ndc, st3d_stream_t stream) {
+    ST3D_CHECK_ARG(verts && R && T && verts_ndc);
+    ST3D_CHECK_ARG(V > 0 && B > 0);
+    const int n = B * V;
+    project_verts_kernel<<<st3d::cdiv(n, 256), 256, 0, st3d::as_stream(stream)>>>(verts, V, R, T, B, inv_tan_half_fov,
+                                                                                  verts_ndc);
+    ST3D_LAUNCH_CHECK();
+    return ST3D_OK;
+}
+
+extern "C" size_t st3d_raster_workspace_bytes(int B, int F) { return (size_t)B * (size_t)F * 3 * sizeof(float4); }
+
+extern "C" int st3d_raster_fwd(const float *verts_ndc, const int32_t *faces, int B, int V, int F, int S, void *workspace,
+                               size_t workspace_bytes, int32_t *pix_to_face, float *zbuf, float *bary, float *dists,
+                               st3d_stream_t stream) {
+    ST3D_CHECK_ARG(verts_ndc && faces && workspace && pix_to_face && zbuf && bary && dists);
+    ST3D_CHECK_ARG(B > 0 && V > 0 && F > 0 && S > 0);
+    ST3D_CHECK_ARG(workspace_bytes >= st3d_raster_workspace_bytes(B, F));
+    ST3D_CHECK_ARG(((uintptr_t)workspace & 15) == 0);
+    hipStream_t s = st3d::as_stream(stream);
+    float4 *rec = reinterpret_cast<float4 *>(workspace);
+    face_setup_kernel<<<st3d::cdiv((long)B * F, 256), 256, 0, s>>>(verts_ndc, faces, B, V, F, rec);
+    ST3D_LAUNCH_CHECK();
+    const int tiles = st3d::cdiv(S, TILE);
+    raster_tile_kernel<<<dim3(tiles, tiles, B), 256, 0, s>>>(rec, F, S, pix_to_face, zbuf, bary, dists);
+    ST3D_LAUNCH_CHECK();
+    return ST3D_OK;
+}

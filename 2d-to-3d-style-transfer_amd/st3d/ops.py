@@ -1,0 +1,179 @@
+"""Tensor-level wrappers over the C ABI (one function per include/st3d.h entry point).
+PyTorch owns the device memory and the stream; every call goes to libst3d.so."""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+from ._lib import call, dptr, stream_ptr
+
+F32, I32, U8 = torch.float32, torch.int32, torch.uint8
+INV_TAN_HALF_FOV = float(1.0 / math.tan(math.radians(60.0) / 2.0))   # FoVPerspectiveCameras default fov=60
+
+
+def _f32c(t):
+    return t.detach().to(F32).contiguous()
+
+
+# ------------------------------------------------------------------ render
+def project_verts(verts, R, T):
+    """verts (V,3), R (B,3,3), T (B,3) -> (B,V,3) (x_ndc, y_ndc, z_view)."""
+    verts, R, T = _f32c(verts), _f32c(R), _f32c(T)
+    B, V = R.shape[0], verts.shape[0]
+    out = torch.empty((B, V, 3), dtype=F32, device=verts.device)
+    call("st3d_project_verts", dptr(verts), V, dptr(R), dptr(T), B, INV_TAN_HALF_FOV, dptr(out), stream_ptr())
+    return out
+
+
+def raster_fwd(verts_ndc, faces_i32, S):
+    """-> pix_to_face (B,S,S) int32, zbuf (B,S,S), bary (B,S,S,3), dists (B,S,S)."""
+    B, V, _ = verts_ndc.shape
+    F = faces_i32.shape[0]
+    dev = verts_ndc.device
+    ws_bytes = _lib.load().st3d_raster_workspace_bytes(B, F)
+    ws = torch.empty((ws_bytes // 4,), dtype=F32, device=dev)
+    p2f = torch.empty((B, S, S), dtype=I32, device=dev)
+    zbuf = torch.empty((B, S, S), dtype=F32, device=dev)
+    bary = torch.empty((B, S, S, 3), dtype=F32, device=dev)
+    dists = torch.empty((B, S, S), dtype=F32, device=dev)
+    call("st3d_raster_fwd", dptr(verts_ndc, F32), dptr(faces_i32, I32), B, V, F, S, dptr(ws), ws_bytes, dptr(p2f),
+         dptr(zbuf), dptr(bary), dptr(dists), stream_ptr())
+    return p2f, zbuf, bary, dists
+
+
+def shade_fwd(frag, verts_uvs, faces_uvs_i32, texture):
+    p2f, zbuf, bary, dists = frag
+    B, S, _ = p2f.shape
+    T = texture.shape[0]
+    rgb = torch.empty((B, 3, S, S), dtype=F32, device=p2f.device)
+    mask = torch.empty((B, 1, S, S), dtype=F32, device=p2f.device)
+    call("st3d_shade_fwd", dptr(p2f, I32), dptr(bary, F32), dptr(zbuf, F32), dptr(dists, F32), dptr(verts_uvs, F32),
+         dptr(faces_uvs_i32, I32), dptr(texture, F32), B, S, T, faces_uvs_i32.shape[0], verts_uvs.shape[0], dptr(rgb),
+         dptr(mask), stream_ptr())
+    return rgb, mask
+
+
+def shade_bwd(grad_rgb, frag, verts_uvs, faces_uvs_i32, texture, grad_texture=None, want_uv=False):
+    p2f, zbuf, bary, dists = frag
+    B, S, _ = p2f.shape
+    T = texture.shape[0]
+    if grad_texture is None:
+        grad_texture = torch.zeros((T, T, 3), dtype=F32, device=p2f.device)
+    guv = torch.empty((B, S, S, 2), dtype=F32, device=p2f.device) if want_uv else None
+    grad_rgb = grad_rgb.contiguous()
+    call("st3d_shade_bwd", dptr(grad_rgb, F32), dptr(p2f, I32), dptr(bary, F32), dptr(zbuf, F32), dptr(dists, F32),
+         dptr(verts_uvs, F32), dptr(faces_uvs_i32, I32), dptr(texture, F32), B, S, T, faces_uvs_i32.shape[0],
+         verts_uvs.shape[0], dptr(grad_texture, F32), dptr(guv), stream_ptr())
+    return (grad_texture, guv) if want_uv else grad_texture
+
+
+def apply_background(img, mask, bg=None):
+    B, _, S, _ = img.shape
+    out = torch.empty_like(img)
+    bgb = 1 if (bg is None or bg.dim() == 3 or bg.shape[0] == 1) else B
+    call("st3d_apply_background", dptr(img.contiguous(), F32), dptr(mask.contiguous(), F32),
+         dptr(bg.contiguous(), F32) if bg is not None else None, bgb, B, S, dptr(out), stream_ptr())
+    return out
+
+
+# ------------------------------------------------------------------ conv / pool
+def conv3x3_pack(w):
+    """w (Cout,Cin,3,3) -> (w_fwd_packed, w_dgrad_packed) flat float tensors."""
+    w = _f32c(w)
+    Cout, Cin = w.shape[:2]
+    n = _lib.load().st3d_conv3x3_packed_floats(Cout, Cin)
+    wf = torch.empty((n,), dtype=F32, device=w.device)
+    wd = torch.empty((n,), dtype=F32, device=w.device)
+    call("st3d_conv3x3_pack", dptr(w), Cout, Cin, dptr(wf), dptr(wd), stream_ptr())
+    return wf, wd
+
+
+def conv3x3_fwd(x, wf, bias, Cout, relu=True):
+    N, Cin, H, W = x.shape
+    y = torch.empty((N, Cout, H, W), dtype=F32, device=x.device)
+    call("st3d_conv3x3_fwd", dptr(x.contiguous(), F32), dptr(wf, F32), dptr(bias, F32) if bias is not None else None,
+         dptr(y), N, Cin, Cout, H, W, 1 if relu else 0, stream_ptr())
+    return y
+
+
+def conv3x3_dgrad(gy, act, wd, Cin):
+    N, Cout, H, W = gy.shape
+    gx = torch.empty((N, Cin, H, W), dtype=F32, device=gy.device)
+    call("st3d_conv3x3_dgrad", dptr(gy.contiguous(), F32), dptr(act, F32) if act is not None else None, dptr(wd, F32),
+         dptr(gx), N, Cin, Cout, H, W, stream_ptr())
+    return gx
+
+
+def conv3x3_dgrad_unpool(gy_pooled, pool_idx, pooled, wd, Cin):
+    N, Cout, Hp, Wp = gy_pooled.shape
+    H, W = 2 * Hp, 2 * Wp
+    gx = torch.empty((N, Cin, H, W), dtype=F32, device=gy_pooled.device)
+    call("st3d_conv3x3_dgrad_unpool", dptr(gy_pooled.contiguous(), F32), dptr(pool_idx, U8), dptr(pooled, F32),
+         dptr(wd, F32), dptr(gx), N, Cin, Cout, H, W, stream_ptr())
+    return gx
+
+
+def maxpool2x2(y, want_idx=True):
+    N, C, H, W = y.shape
+    p = torch.empty((N, C, H // 2, W // 2), dtype=F32, device=y.device)
+    idx = torch.empty((N, C, H // 2, W // 2), dtype=U8, device=y.device) if want_idx else None
+    call("st3d_maxpool2x2_fwd", dptr(y.contiguous(), F32), dptr(p), dptr(idx), N, C, H, W, stream_ptr())
+    return (p, idx) if want_idx else p
+
+
+# ------------------------------------------------------------------ gram / losses
+def gram_fwd(feat):
+    """(B,C,H,W) or (B,C,HW) -> (B,C,C) unnormalised Gram (style_transfer.py:31-35)."""
+    B, C = feat.shape[:2]
+    HW = feat[0, 0].numel()
+    ws_bytes = _lib.load().st3d_gram_workspace_bytes(B, C, HW)
+    ws = torch.empty((max(ws_bytes // 4, 1),), dtype=F32, device=feat.device)
+    g = torch.empty((B, C, C), dtype=F32, device=feat.device)
+    call("st3d_gram_fwd", dptr(feat.contiguous(), F32), B, C, HW, dptr(ws), ws_bytes, dptr(g), stream_ptr())
+    return g
+
+
+def gram_bwd(D, feat, coef, out=None):
+    B, C = feat.shape[:2]
+    HW = feat[0, 0].numel()
+    acc = 1
+    if out is None:
+        out = torch.empty_like(feat)
+        acc = 0
+    call("st3d_gram_bwd", dptr(D.contiguous(), F32), dptr(feat.contiguous(), F32), B, C, HW, float(coef), acc, dptr(out),
+         stream_ptr())
+    return out
+
+
+def sqdiff_sum(a, b, scale=1.0, want_diff=False):
+    n, nb = a.numel(), b.numel()
+    parts = torch.empty((_lib.load().st3d_reduce_partials(),), dtype=F32, device=a.device)
+    out = torch.zeros((1,), dtype=F32, device=a.device)
+    D = torch.empty_like(a) if want_diff else None
+    call("st3d_sqdiff_sum", dptr(a.contiguous(), F32), dptr(b.contiguous(), F32), n, nb, float(scale), dptr(D),
+         dptr(parts), dptr(out), stream_ptr())
+    return (out, D) if want_diff else out
+
+
+def masked_mse(rendered, target, mask, want_grad=True):
+    B, _, S, _ = rendered.shape
+    parts = torch.empty((_lib.load().st3d_reduce_partials(),), dtype=F32, device=rendered.device)
+    out = torch.zeros((1,), dtype=F32, device=rendered.device)
+    g = torch.empty_like(rendered) if want_grad else None
+    call("st3d_masked_mse", dptr(rendered.contiguous(), F32), dptr(target.contiguous(), F32), dptr(mask.contiguous(), F32),
+         B, S, dptr(g), dptr(parts), dptr(out), stream_ptr())
+    return out, g
+
+
+def adam_step(p, g, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8):
+    call("st3d_adam_step", dptr(p, F32), dptr(g.contiguous(), F32), dptr(m, F32), dptr(v, F32), p.numel(), int(step),
+         float(lr), float(b1), float(b2), float(eps), stream_ptr())
+
+
+def device_info(device=0):
+    cu = ctypes.c_int(0)
+    hbm = ctypes.c_size_t(0)
+    name = ctypes.create_string_buffer(128)
+    call("st3d_device_info", device, ctypes.byref(cu), ctypes.byref(hbm), name, 128)
+    return {"cu_count": cu.value, "hbm_bytes": hbm.value, "name": name.value.decode()}

@@ -1,0 +1,234 @@
+"""Frozen VGG-19 feature extractor on libst3d (utils.py:48-52 get_vgg, style_transfer.py:10-27).
+
+``Vgg19Features`` keeps the duck type the reference's ``get_features`` walks -- an ordered
+``_modules`` dict with keys '0'..'36' (torchvision ``vgg19().features`` numbering, SURVEY.md
+A.7) whose values are callables -- so the reference loop ``for name, layer in
+model._modules.items(): x = layer(x)`` still works on it (each module is one HIP launch),
+while ``get_features`` / ``compute_perceptual_loss`` recognise the object and dispatch to the
+fused plan (``PerceptualPlan``: st3d_plan_* in include/st3d.h).
+
+Weights: the reference downloads IMAGENET1K_V1 (utils.py:49), which is impossible offline.
+``get_vgg()`` loads a local state_dict when ``ST3D_VGG19_WEIGHTS`` (or ``weights=``) names one
+(torchvision key layout ``features.<idx>.weight`` or ``<idx>.weight``), otherwise seeded
+He-normal weights -- the same generator sequence as the oracle's
+``synthetic_vgg19_state`` so both sides can be driven with identical parameters.
+"""
+import ctypes
+import math
+import os
+from collections import OrderedDict
+
+import torch
+
+from . import _lib, ops
+from ._lib import call, dptr, stream_ptr
+
+VGG19_CFG = [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M"]
+DEFAULT_TAPS = {"0": "conv1_1", "5": "conv2_1", "10": "conv3_1", "19": "conv4_1", "21": "conv4_2", "28": "conv5_1"}
+STYLE_TAP_MODULES = (0, 5, 10, 19, 28)
+CONTENT_TAP_MODULE = 21
+
+
+def synthetic_state(seed=0, bias_scale=0.05):
+    g = torch.Generator().manual_seed(seed)
+    state, cin, idx = {}, 3, 0
+    for v in VGG19_CFG:
+        if v == "M":
+            idx += 1
+            continue
+        state[f"{idx}.weight"] = torch.randn((v, cin, 3, 3), generator=g) * math.sqrt(2.0 / (cin * 9))
+        state[f"{idx}.bias"] = torch.randn((v,), generator=g) * bias_scale
+        cin = v
+        idx += 2
+    return state
+
+
+class _Conv:
+    """conv3x3(pad 1); its ReLU is the next module.  When called from the generic
+    ``_modules`` walk the pre-ReLU value is materialised (one launch with relu=0)."""
+    kind = "conv"
+
+    def __init__(self, owner, idx, cin, cout):
+        self.owner, self.idx, self.cin, self.cout = owner, idx, cin, cout
+        self.wf = self.wd = self.bias = None
+
+    def __call__(self, x):
+        return ops.conv3x3_fwd(x, self.wf, self.bias, self.cout, relu=False)
+
+
+class _ReLU:
+    kind = "relu"
+    inplace = True
+
+    def __call__(self, x):
+        return x.relu_()        # in place, as torchvision builds it (the tap tensor is overwritten)
+
+
+class _Pool:
+    kind = "pool"
+
+    def __call__(self, x):
+        return ops.maxpool2x2(x, want_idx=False)
+
+
+class Vgg19Features:
+    def __init__(self, state=None, device="cuda"):
+        self.device = torch.device(device)
+        self._modules = OrderedDict()
+        cin, idx = 3, 0
+        for v in VGG19_CFG:
+            if v == "M":
+                self._modules[str(idx)] = _Pool()
+                idx += 1
+            else:
+                self._modules[str(idx)] = _Conv(self, idx, cin, v)
+                self._modules[str(idx + 1)] = _ReLU()
+                cin = v
+                idx += 2
+        h = ctypes.c_void_p()
+        call("st3d_vgg_create", ctypes.byref(h))
+        self._h = h
+        self._plans = {}
+        self.load_state_dict(state if state is not None else synthetic_state(0))
+
+    def load_state_dict(self, state):
+        for name, mod in self._modules.items():
+            if mod.kind != "conv":
+                continue
+            w = state.get(f"{name}.weight", state.get(f"features.{name}.weight"))
+            b = state.get(f"{name}.bias", state.get(f"features.{name}.bias"))
+            if w is None or b is None:
+                raise KeyError(f"state_dict lacks conv {name}")
+            w = w.detach().to(self.device, torch.float32).contiguous()
+            b = b.detach().to(self.device, torch.float32).contiguous()
+            assert tuple(w.shape) == (mod.cout, mod.cin, 3, 3), (name, tuple(w.shape))
+            mod.wf, mod.wd = ops.conv3x3_pack(w)
+            mod.bias = b
+            call("st3d_vgg_set_conv", self._h, int(name), dptr(w), dptr(b), stream_ptr())
+        torch.cuda.synchronize()
+
+    def parameters(self):
+        return iter(())          # frozen (utils.py:50-51)
+
+    def to(self, *a, **k):
+        return self
+
+    def eval(self):
+        return self
+
+    def plan(self, B, S):
+        key = (int(B), int(S))
+        if key not in self._plans:
+            self._plans[key] = PerceptualPlan(self, *key)
+        return self._plans[key]
+
+    def __del__(self):
+        try:
+            for p in list(getattr(self, "_plans", {}).values()):
+                p.close()
+            if getattr(self, "_h", None):
+                _lib.load().st3d_vgg_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class PerceptualPlan:
+    """Workspace + fixed launch sequence for batch B at SxS (st3d_plan in include/st3d.h)."""
+
+    def __init__(self, vgg, B, S):
+        self.vgg, self.B, self.S = vgg, B, S
+        h = ctypes.c_void_p()
+        call("st3d_plan_create", ctypes.byref(h), vgg._h, B, S)
+        self._h = h
+        self._content_key = self._style_key = None
+        self.loss_buf = torch.zeros((3,), dtype=torch.float32, device=vgg.device)
+
+    def close(self):
+        if self._h:
+            _lib.load().st3d_plan_destroy(self._h)
+            self._h = None
+
+    def bytes(self):
+        return _lib.load().st3d_plan_bytes(self._h)
+
+    def forward(self, imgs, upto=28):
+        imgs = imgs.detach().to(torch.float32).contiguous()
+        call("st3d_plan_forward", self._h, dptr(imgs), imgs.shape[0], int(upto), stream_ptr())
+        self._n = imgs.shape[0]
+
+    def activation(self, module_idx, n=None):
+        """Tensor VIEW of the plan's buffer after `module_idx` (valid until the next forward)."""
+        p = ctypes.c_void_p()
+        C, H, W = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        call("st3d_plan_activation", self._h, int(module_idx), ctypes.byref(p), ctypes.byref(C), ctypes.byref(H),
+             ctypes.byref(W))
+        n = n or self._n
+        return _wrap_device_ptr(p.value, (n, C.value, H.value, W.value), self.vgg.device)
+
+    @staticmethod
+    def _key(t):
+        return (t.data_ptr(), t._version, tuple(t.shape))
+
+    def set_content(self, content, force=False):
+        k = self._key(content)
+        if force or k != self._content_key:
+            c = content.detach().to(torch.float32).contiguous()
+            call("st3d_plan_set_content", self._h, dptr(c), c.shape[0], stream_ptr())
+            self._content_key = k
+
+    def set_style(self, style, n, force=False):
+        k = self._key(style) + (n,)
+        if force or k != self._style_key:
+            s = style.detach().to(torch.float32).contiguous()
+            sb = s.shape[0]
+            if sb > 1 and s.stride(0) == 0:
+                sb = 1
+            if sb > 1 and bool((s[0:1] == s).all()):      # the reference repeats one image (second_approach.py:157)
+                sb = 1
+            s = s[:1].contiguous() if sb == 1 else s
+            call("st3d_plan_set_style", self._h, dptr(s), sb, n, stream_ptr())
+            self._style_key = k
+
+    def loss(self, current, style_weight, content_weight, batch_denom=None, want_grad=True):
+        """-> (loss_buf view [total, content, style], grad (n,3,S,S) or None)."""
+        cur = current.detach().to(torch.float32).contiguous()
+        n = cur.shape[0]
+        grad = torch.empty_like(cur) if want_grad else None
+        call("st3d_plan_loss", self._h, dptr(cur), n, int(batch_denom or n), float(style_weight), float(content_weight),
+             dptr(self.loss_buf), dptr(grad), stream_ptr())
+        return self.loss_buf, grad
+
+    def profile(self, enable):
+        call("st3d_plan_profile", self._h, 1 if enable else 0)
+
+    def profile_read(self):
+        ms = (ctypes.c_float * 6)()
+        nl = (ctypes.c_int * 6)()
+        call("st3d_plan_profile_read", self._h, ms, nl)
+        names = ("conv_fwd", "conv_dgrad", "pool", "gram_fwd", "gram_bwd", "elementwise")
+        return {k: {"ms": ms[i], "launches": nl[i]} for i, k in enumerate(names)}
+
+
+class _DevArray:
+    """__cuda_array_interface__ shim so torch can view a raw device pointer without a copy."""
+
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = {"data": (ptr, False), "shape": tuple(shape), "typestr": "<f4", "version": 3,
+                                         "strides": None}
+
+
+def _wrap_device_ptr(ptr, shape, device):
+    return torch.as_tensor(_DevArray(ptr, shape), device=device)
+
+
+def get_vgg(weights=None, device="cuda", seed=0):
+    """Drop-in for utils.py:48-52.  `weights`: path to a local state_dict (or env
+    ST3D_VGG19_WEIGHTS); default = seeded synthetic weights (no download is attempted)."""
+    path = weights or os.environ.get("ST3D_VGG19_WEIGHTS")
+    state = None
+    if path:
+        state = torch.load(path, map_location="cpu", weights_only=True)
+    else:
+        state = synthetic_state(seed)
+    return Vgg19Features(state, device=device)

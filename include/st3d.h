@@ -1,0 +1,183 @@
+/*
+ * st3d.h -- C ABI of libst3d.so: the MI355X (gfx950) device half of the 2D->3D
+ * style-transfer optimisation step.
+ *
+ * The reference (EmaMule/2D-to-3D-Style-Transfer) is pure Python and has no FFI of its
+ * own: what it binds for this path is PyTorch3D's `_C` extension, torchvision/ATen
+ * operators and torch.optim.Adam.  Each entry point below cites the reference call site
+ * (file:line, relative to the reference tree) whose device work it replaces.
+ *
+ * Conventions
+ *   - extern "C"; plain pointers and sizes; no torch / C++ types.
+ *   - every pointer is a DEVICE pointer owned by the caller unless it is marked `host`;
+ *     opaque handles (st3d_vgg, st3d_plan) own their workspaces (hipMalloc at create).
+ *   - every function returns 0 (ST3D_OK) or a negative ST3D_E_* code; st3d_last_error()
+ *     returns a thread-local message.  No exceptions cross the boundary.
+ *   - kernels are asynchronous on the given stream (a hipStream_t passed as void*; NULL =
+ *     the default stream).  Handles are not thread-safe (the reference is single-threaded).
+ *   - tensors are fp32, contiguous; images are NCHW exactly as utils.py:70-76 builds them.
+ */
+#ifndef ST3D_H
+#define ST3D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ST3D_OK 0
+#define ST3D_E_INVALID (-1) /* bad argument / shape */
+#define ST3D_E_HIP (-2)     /* a HIP runtime call failed */
+#define ST3D_E_NOMEM (-3)   /* workspace allocation failed */
+#define ST3D_E_STATE (-4)   /* call order violated (e.g. loss before targets) */
+
+typedef void *st3d_stream_t;
+
+int st3d_version(void);
+const char *st3d_last_error(void);
+/* host out-params; any may be NULL */
+int st3d_device_info(int device, int *cu_count, size_t *hbm_bytes, char *name, int name_len);
+
+/* ------------------------------------------------------------------ render: utils.py:65-77
+ * (render_meshes -> PyTorch3D MeshRasterizer/SoftPhongShader configured at
+ *  first_approach.py:107-113, second_approach.py:101-108: blur_radius=0, faces_per_pixel=1,
+ *  ambient lights, FoV perspective cameras).  All B views of a batch go through one launch. */
+
+/* verts (V,3) world; R (B,3,3), T (B,3) row-vector convention X_view = X R + T
+ * (utils.py:142-149,161-168); out verts_ndc (B,V,3) = (x_ndc, y_ndc, z_view). */
+int st3d_project_verts(const float *verts, int V, const float *R, const float *T, int B,
+                       float inv_tan_half_fov, float *verts_ndc, st3d_stream_t stream);
+
+/* bytes of scratch st3d_raster_fwd needs (per-view packed face records) */
+size_t st3d_raster_workspace_bytes(int B, int F);
+
+/* Hard rasterisation (K=1, blur_radius=0, perspective-correct barycentrics).
+ * faces (F,3) int32.  Outputs per view (B,S,S): pix_to_face int32 (-1 = background; the
+ * reference's int64 is produced by the Python host on request), zbuf, bary (B,S,S,3),
+ * dists (signed squared edge distance), -1 filled on background. */
+int st3d_raster_fwd(const float *verts_ndc, const int32_t *faces, int B, int V, int F, int S,
+                    void *workspace, size_t workspace_bytes, int32_t *pix_to_face, float *zbuf,
+                    float *bary, float *dists, st3d_stream_t stream);
+
+/* Fused TexturesUV.sample_textures + ambient shading + softmax_rgb_blend (K=1) + the
+ * RGB/mask extraction of utils.py:70-72.  texture (T,T,3) HWC as maps_padded()[0]
+ * (utils.py:208), verts_uvs (VT,2), faces_uvs (F,3) int32.
+ * rgb (B,3,S,S), mask (B,1,S,S) = (alpha > 0). */
+int st3d_shade_fwd(const int32_t *pix_to_face, const float *bary, const float *zbuf,
+                   const float *dists, const float *verts_uvs, const int32_t *faces_uvs,
+                   const float *texture, int B, int S, int T, int F, int VT, float *rgb,
+                   float *mask, st3d_stream_t stream);
+
+/* Texture-sampling backward (grid_sampler_2d_backward + blend backward):
+ * grad_rgb (B,3,S,S) -> grad_texture (T,T,3), ACCUMULATED over the B views (caller zeroes).
+ * grad_uv (B,S,S,2) optional (NULL for texture-only optimisation): d loss / d (u,v). */
+int st3d_shade_bwd(const float *grad_rgb, const int32_t *pix_to_face, const float *bary,
+                   const float *zbuf, const float *dists, const float *verts_uvs,
+                   const int32_t *faces_uvs, const float *texture, int B, int S, int T, int F,
+                   int VT, float *grad_texture, float *grad_uv, st3d_stream_t stream);
+
+/* apply_background, utils.py:19-30: out = img*mask + bg*(1-mask); bg (B,3,S,S) or, with
+ * bg_batch == 1, one (3,S,S) image broadcast over the batch.  Optional grad path is the
+ * same kernel applied to the gradient with bg = NULL (out = g*mask). */
+int st3d_apply_background(const float *img, const float *mask, const float *bg, int bg_batch,
+                          int B, int S, float *out, st3d_stream_t stream);
+
+/* ------------------------------------------------------------------ VGG-19 features:
+ * utils.py:48-52 (get_vgg) + style_transfer.py:10-27 (get_features).  conv3x3 pad 1 +
+ * bias + ReLU on fp32 MFMA (v_mfma_f32_32x32x2_f32), maxpool 2x2. */
+
+/* packed-weight sizes in floats for a (Cout,Cin,3,3) filter */
+size_t st3d_conv3x3_packed_floats(int Cout, int Cin);
+/* w (Cout,Cin,3,3) -> w_fwd [9][Cin4][CoutP] and w_dgrad [9][Cout4][CinP] (rotated 180 deg,
+ * channel-transposed); either output may be NULL. */
+int st3d_conv3x3_pack(const float *w, int Cout, int Cin, float *w_fwd, float *w_dgrad,
+                      st3d_stream_t stream);
+/* y = relu?(conv3x3(x, w) + bias): x (N,Cin,H,W), y (N,Cout,H,W) */
+int st3d_conv3x3_fwd(const float *x, const float *w_fwd_packed, const float *bias, float *y,
+                     int N, int Cin, int Cout, int H, int W, int relu, st3d_stream_t stream);
+/* gx = conv3x3^T(mask(gy)): gradient w.r.t. the conv INPUT (weights are frozen,
+ * utils.py:50-51: no wgrad).  gy (N,Cout,H,W) is the gradient w.r.t. the POST-ReLU output;
+ * act (same shape, the saved post-ReLU output) gates it (act>0) when non-NULL. */
+int st3d_conv3x3_dgrad(const float *gy, const float *act, const float *w_dgrad_packed, float *gx,
+                       int N, int Cin, int Cout, int H, int W, st3d_stream_t stream);
+/* As above, but gy is given at POOLED resolution (N,Cout,H/2,W/2) together with the pool's
+ * argmax (uint8 0..3 = dy*2+dx) and pooled values: fuses max-unpool + ReLU gate into the load. */
+int st3d_conv3x3_dgrad_unpool(const float *gy_pooled, const uint8_t *pool_idx, const float *pooled,
+                              const float *w_dgrad_packed, float *gx, int N, int Cin, int Cout,
+                              int H, int W, st3d_stream_t stream);
+/* MaxPool2d(2,2): y (N,C,H,W) -> p (N,C,H/2,W/2) (+ argmax idx, may be NULL) */
+int st3d_maxpool2x2_fwd(const float *y, float *p, uint8_t *idx, int N, int C, int H, int W,
+                        st3d_stream_t stream);
+
+/* ------------------------------------------------------------------ Gram / losses:
+ * style_transfer.py:31-35 (gram_matrix), losses.py:31-42 */
+
+size_t st3d_gram_workspace_bytes(int B, int C, int HW);
+/* gram (B,C,C) = F F^T, F = feat (B,C,HW); unnormalised; split-K fp32 MFMA + ordered
+ * (deterministic) slab reduction. */
+int st3d_gram_fwd(const float *feat, int B, int C, int HW, void *workspace, size_t workspace_bytes,
+                  float *gram, st3d_stream_t stream);
+/* gfeat (B,C,HW) (+)= coef * (D F) with D (B,C,C) symmetric (D = G - S); accumulate != 0 adds
+ * into gfeat. */
+int st3d_gram_bwd(const float *D, const float *feat, int B, int C, int HW, float coef,
+                  int accumulate, float *gfeat, st3d_stream_t stream);
+/* loss_out[0] += scale * sum((a-b)^2) over n elements (b broadcast with period nb, nb | n);
+ * if D != NULL also D = a - b.  Deterministic two-stage reduction through `partials`
+ * (>= st3d_reduce_partials() floats). */
+int st3d_reduce_partials(void);
+int st3d_sqdiff_sum(const float *a, const float *b, size_t n, size_t nb, float scale, float *D,
+                    float *partials, float *loss_out, st3d_stream_t stream);
+/* content loss backward: g (+)= coef * (a - b)  */
+int st3d_axpy_diff(const float *a, const float *b, size_t n, float coef, int accumulate, float *g,
+                   st3d_stream_t stream);
+/* masked MSE of losses.py:68-75 ('texture' branch): loss_out[0] = mean((r*m - t*m)^2) over
+ * B*3*S*S; grad_r = 2*m*m*(r - t)/(B*3*S*S) (may be NULL). */
+int st3d_masked_mse(const float *rendered, const float *target, const float *mask, int B, int S,
+                    float *grad_rendered, float *partials, float *loss_out, st3d_stream_t stream);
+
+/* ------------------------------------------------------------------ optimiser:
+ * torch.optim.Adam defaults (utils.py:185-195, style_transfer.py:57) */
+int st3d_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n,
+                   int step, float lr, float beta1, float beta2, float eps, st3d_stream_t stream);
+
+/* ------------------------------------------------------------------ fused perceptual engine:
+ * losses.py:12-44 (compute_perceptual_loss) and the loop body of style_transfer.py:59-83.
+ * One object per (VGG weights); one plan per (batch, image size). */
+typedef struct st3d_vgg st3d_vgg;
+typedef struct st3d_plan st3d_plan;
+
+int st3d_vgg_create(st3d_vgg **out);
+/* module_idx in torchvision's vgg19().features numbering (0,2,5,7,...,34); w (Cout,Cin,3,3), b (Cout) */
+int st3d_vgg_set_conv(st3d_vgg *vgg, int module_idx, const float *w, const float *b,
+                      st3d_stream_t stream);
+int st3d_vgg_destroy(st3d_vgg *vgg);
+
+int st3d_plan_create(st3d_plan **out, st3d_vgg *vgg, int B, int S);
+int st3d_plan_destroy(st3d_plan *plan);
+size_t st3d_plan_bytes(const st3d_plan *plan);
+/* forward of imgs (n,3,S,S), n <= B, through modules 0..upto_module (post-ReLU taps) */
+int st3d_plan_forward(st3d_plan *plan, const float *imgs, int n, int upto_module, st3d_stream_t stream);
+/* device pointer + shape of the activation after module_idx (a conv index = its post-ReLU
+ * output, a pool index = the pooled output) of the last st3d_plan_forward */
+int st3d_plan_activation(st3d_plan *plan, int module_idx, float **ptr, int *C, int *H, int *W);
+/* targets (losses.py:18-25): conv4_2 features of content (B,3,S,S); Grams of style
+ * (style_batch == 1: one image broadcast over the batch, as second_approach.py:157 repeats it) */
+int st3d_plan_set_content(st3d_plan *plan, const float *content, int n, st3d_stream_t stream);
+int st3d_plan_set_style(st3d_plan *plan, const float *style, int style_batch, int n, st3d_stream_t stream);
+/* loss (losses.py:28-42) of current (n,3,S,S) and, if grad_current != NULL, d loss/d current.
+ * batch_denom = the batch size the means divide by (n, or the GLOBAL batch when views are
+ * sharded over ranks).  loss_out: device float[3] = {total, content_loss, style_loss}. */
+int st3d_plan_loss(st3d_plan *plan, const float *current, int n, int batch_denom, float style_weight,
+                   float content_weight, float *loss_out, float *grad_current, st3d_stream_t stream);
+/* per-kernel-family timing of the next calls (HIP events on the call's stream): enable, then
+ * read accumulated milliseconds + launch counts; families: 0 conv_fwd 1 conv_dgrad 2 pool
+ * 3 gram_fwd 4 gram_bwd 5 loss/elementwise */
+int st3d_plan_profile(st3d_plan *plan, int enable);
+int st3d_plan_profile_read(st3d_plan *plan, float *ms_out /*host [6]*/, int *launches_out /*host [6]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ST3D_H */

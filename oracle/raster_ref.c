@@ -1,0 +1,295 @@
+/*
+ * oracle/raster_ref.c -- TEST INFRASTRUCTURE ONLY (never linked into, imported by or
+ * called from the product path; see DESIGN.md "Oracle").
+ *
+ * Plain-C CPU restatement of the render half of the reference hot path:
+ *   utils.py:65-77 render_meshes  ->  PyTorch3D MeshRasterizer + SoftPhongShader +
+ *   TexturesUV.sample_textures + softmax_rgb_blend, with the settings the reference
+ *   fixes at first_approach.py:107-113 / second_approach.py:101-108
+ *   (blur_radius=0.0, faces_per_pixel=1, AmbientLights, FoVPerspectiveCameras defaults).
+ *
+ * PyTorch3D is a third-party dependency that is NOT vendored under /root/reference and is
+ * not installed (version unpinned: no requirements/lock file).  The arithmetic below
+ * restates its published naive-CPU algorithm (rasterize_meshes_cpu.cpp, geometry_utils.h,
+ * blending.py softmax_rgb_blend, TexturesUV.sample_textures + ATen grid_sampler_2d) as
+ * summarised in SURVEY.md Appendix A.  PARITY UNPINNED for this file: the reference holds
+ * no golden vectors for the render path; it is pinned by analytic tests only
+ * (tests/test_oracle_raster.py).
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off: no FMA contraction, so the HIP
+ * kernels, built the same way, can be compared bit-for-bit on the integer/geometry outputs).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define K_EPS 1e-8f
+
+/* ---------------------------------------------------------------- cameras (A.1) */
+
+/* verts (V,3) world; R (3,3) row-major, T (3): X_view = X_world . R + T  (row-vector
+ * convention, utils.py:142-149,161-168).  out (V,3) = (x_ndc, y_ndc, z_view) with
+ * x_ndc = s*x_v/z_v, s = 1/tan(fov/2) (FoVPerspectiveCameras defaults fov=60deg, aspect 1). */
+void ref_project_verts(const float *verts, int V, const float *R, const float *T,
+                       float inv_tan_half_fov, float *out)
+{
+    for (int v = 0; v < V; ++v) {
+        const float x = verts[3 * v + 0], y = verts[3 * v + 1], z = verts[3 * v + 2];
+        const float xv = x * R[0] + y * R[3] + z * R[6] + T[0];
+        const float yv = x * R[1] + y * R[4] + z * R[7] + T[1];
+        const float zv = x * R[2] + y * R[5] + z * R[8] + T[2];
+        out[3 * v + 0] = (inv_tan_half_fov * xv) / zv;
+        out[3 * v + 1] = (inv_tan_half_fov * yv) / zv;
+        out[3 * v + 2] = zv;
+    }
+}
+
+/* ---------------------------------------------------------------- geometry (A.2) */
+
+static inline float edge_fn(float px, float py, float ax, float ay, float bx, float by)
+{
+    return (px - ax) * (by - ay) - (py - ay) * (bx - ax);
+}
+
+static inline float point_line_dist2(float px, float py, float ax, float ay, float bx, float by)
+{
+    const float bax = bx - ax, bay = by - ay;
+    const float l2 = bax * bax + bay * bay;
+    if (l2 <= K_EPS) {
+        const float dx = px - bx, dy = py - by;
+        return dx * dx + dy * dy;
+    }
+    float t = (bax * (px - ax) + bay * (py - ay)) / l2;
+    t = t < 0.f ? 0.f : (t > 1.f ? 1.f : t);
+    const float qx = ax + t * bax, qy = ay + t * bay;
+    const float dx = qx - px, dy = qy - py;
+    return dx * dx + dy * dy;
+}
+
+static inline float pix_to_ndc(int i, int S)
+{
+    return -1.0f + (2.0f * (float)i + 1.0f) / (float)S;
+}
+
+/*
+ * Naive rasteriser, K = faces_per_pixel = 1, perspective_correct = 1, no bary clipping,
+ * no back-face culling, bbox padded by sqrt(blur_radius).
+ * verts_ndc (V,3) from ref_project_verts; faces (F,3) int32.
+ * Outputs (S,S): pix_to_face int32 (-1 = background), zbuf, bary (S,S,3), dists (signed
+ * squared distance to the nearest edge; negative inside); -1 fill elsewhere.
+ */
+void ref_rasterize(const float *verts_ndc, const int32_t *faces, int F, int S,
+                   float blur_radius, int nthreads,
+                   int32_t *pix_to_face, float *zbuf, float *bary, float *dists)
+{
+    const float pad = sqrtf(blur_radius);
+    (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+    for (int yi = 0; yi < S; ++yi) {
+        const float yf = pix_to_ndc(S - 1 - yi, S);
+        for (int xi = 0; xi < S; ++xi) {
+            const float xf = pix_to_ndc(S - 1 - xi, S);
+            int best_f = -1;
+            float best_z = 0.f, best_d = 0.f, bw0 = 0.f, bw1 = 0.f, bw2 = 0.f;
+            for (int f = 0; f < F; ++f) {
+                const int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
+                const float x0 = verts_ndc[3 * i0], y0 = verts_ndc[3 * i0 + 1], z0 = verts_ndc[3 * i0 + 2];
+                const float x1 = verts_ndc[3 * i1], y1 = verts_ndc[3 * i1 + 1], z1 = verts_ndc[3 * i1 + 2];
+                const float x2 = verts_ndc[3 * i2], y2 = verts_ndc[3 * i2 + 1], z2 = verts_ndc[3 * i2 + 2];
+                const float xmin = fminf(x0, fminf(x1, x2)) - pad, xmax = fmaxf(x0, fmaxf(x1, x2)) + pad;
+                const float ymin = fminf(y0, fminf(y1, y2)) - pad, ymax = fmaxf(y0, fmaxf(y1, y2)) + pad;
+                if (xf > xmax || xf < xmin || yf > ymax || yf < ymin) continue;
+                const float zmax = fmaxf(z0, fmaxf(z1, z2));
+                if (zmax < K_EPS) continue;                       /* face fully behind the camera */
+                const float face_area = edge_fn(x2, y2, x0, y0, x1, y1);
+                if (face_area <= K_EPS && face_area >= -K_EPS) continue;
+                const float area = face_area + K_EPS;
+                const float w0 = edge_fn(xf, yf, x1, y1, x2, y2) / area;
+                const float w1 = edge_fn(xf, yf, x2, y2, x0, y0) / area;
+                const float w2 = edge_fn(xf, yf, x0, y0, x1, y1) / area;
+                /* perspective correction */
+                const float t0 = w0 * z1 * z2;
+                const float t1 = z0 * w1 * z2;
+                const float t2 = z0 * z1 * w2;
+                const float den = fmaxf(t0 + t1 + t2, K_EPS);
+                const float b0 = t0 / den, b1 = t1 / den, b2 = t2 / den;
+                const float pz = b0 * z0 + b1 * z1 + b2 * z2;
+                if (pz < 0.f) continue;
+                const int inside = (b0 > 0.f) && (b1 > 0.f) && (b2 > 0.f);
+                if (!inside) {
+                    /* blur_radius == 0: an outside pixel can never satisfy d < blur. */
+                    if (blur_radius <= 0.f) continue;
+                }
+                const float d01 = point_line_dist2(xf, yf, x0, y0, x1, y1);
+                const float d12 = point_line_dist2(xf, yf, x1, y1, x2, y2);
+                const float d20 = point_line_dist2(xf, yf, x2, y2, x0, y0);
+                const float d = fminf(d01, fminf(d12, d20));
+                if (!inside && d >= blur_radius) continue;
+                const float sd = inside ? -d : d;
+                if (best_f < 0 || pz < best_z) {            /* ties keep the smaller face index */
+                    best_f = f; best_z = pz; best_d = sd; bw0 = b0; bw1 = b1; bw2 = b2;
+                }
+            }
+            const size_t p = (size_t)yi * S + xi;
+            if (best_f >= 0) {
+                pix_to_face[p] = best_f; zbuf[p] = best_z; dists[p] = best_d;
+                bary[3 * p] = bw0; bary[3 * p + 1] = bw1; bary[3 * p + 2] = bw2;
+            } else {
+                pix_to_face[p] = -1; zbuf[p] = -1.f; dists[p] = -1.f;
+                bary[3 * p] = -1.f; bary[3 * p + 1] = -1.f; bary[3 * p + 2] = -1.f;
+            }
+        }
+    }
+}
+
+/* ---------------------------------------------------------------- texture sampling (A.3) */
+
+typedef struct { int x0, x1, r0, r1; float wx0, wx1, wy0, wy1; int vx0, vx1, vy0, vy1; } bilerp_t;
+
+/* UV -> bilinear footprint in ORIGINAL texture rows (map flipped vertically before
+ * grid_sample(align_corners=True, padding_mode='border')). */
+static inline void uv_footprint(float u, float v, int T, bilerp_t *o, float *ix_out, float *iy_out,
+                                int *clamped_x, int *clamped_y)
+{
+    const float gx = u * 2.0f - 1.0f, gy = v * 2.0f - 1.0f;
+    float ix = ((gx + 1.0f) / 2.0f) * (float)(T - 1);
+    float iy = ((gy + 1.0f) / 2.0f) * (float)(T - 1);
+    *clamped_x = 0; *clamped_y = 0;
+    if (!(ix >= 0.f)) { ix = 0.f; *clamped_x = 1; } else if (ix > (float)(T - 1)) { ix = (float)(T - 1); *clamped_x = 1; }
+    if (!(iy >= 0.f)) { iy = 0.f; *clamped_y = 1; } else if (iy > (float)(T - 1)) { iy = (float)(T - 1); *clamped_y = 1; }
+    const float fx = floorf(ix), fy = floorf(iy);
+    o->x0 = (int)fx; o->x1 = o->x0 + 1;
+    const int yf0 = (int)fy, yf1 = yf0 + 1;            /* rows of the FLIPPED map */
+    o->wx1 = ix - fx; o->wx0 = 1.0f - o->wx1;         /* = (x1 - ix) */
+    o->wy1 = iy - fy; o->wy0 = 1.0f - o->wy1;
+    o->vx0 = o->x0 >= 0 && o->x0 < T; o->vx1 = o->x1 >= 0 && o->x1 < T;
+    o->vy0 = yf0 >= 0 && yf0 < T;     o->vy1 = yf1 >= 0 && yf1 < T;
+    o->r0 = (T - 1) - yf0; o->r1 = (T - 1) - yf1;     /* original rows */
+    *ix_out = ix; *iy_out = iy;
+}
+
+/* blend constants: softmax_rgb_blend with BlendParams defaults sigma=gamma=1e-4, bg=(1,1,1),
+ * znear=1, zfar=100 (SoftPhongShader defaults), K=1. */
+#define BLEND_SIGMA 1e-4f
+#define BLEND_GAMMA 1e-4f
+#define BLEND_EPS   1e-10f
+#define ZNEAR 1.0f
+#define ZFAR  100.0f
+
+static inline void blend_k1(float dist, float z, float *prob_out, float *wnum_out, float *delta_out, float *denom_out)
+{
+    const float prob = 1.0f / (1.0f + expf(dist / BLEND_SIGMA));   /* sigmoid(-dist/sigma) */
+    const float z_inv = (ZFAR - z) / (ZFAR - ZNEAR);
+    const float z_max = fmaxf(z_inv, BLEND_EPS);
+    const float wnum = prob * expf((z_inv - z_max) / BLEND_GAMMA);
+    const float delta = fmaxf(expf((BLEND_EPS - z_max) / BLEND_GAMMA), BLEND_EPS);
+    *prob_out = prob; *wnum_out = wnum; *delta_out = delta; *denom_out = wnum + delta;
+}
+
+/*
+ * Fused shade: UV interpolation -> bilinear sample -> ambient (colour = texel) -> softmax
+ * blend (K=1) -> CHW RGB + mask exactly as utils.py:70-72 lays them out.
+ * texture (T,T,3) HWC; verts_uvs (VT,2); faces_uvs (F,3) int32.
+ * rgb (3,S,S), mask (S,S) = (alpha > 0).
+ */
+void ref_shade_fwd(const int32_t *pix_to_face, const float *bary, const float *zbuf, const float *dists,
+                   const float *verts_uvs, const int32_t *faces_uvs, const float *texture,
+                   int S, int T, float *rgb, float *mask)
+{
+    const size_t HW = (size_t)S * S;
+    for (size_t p = 0; p < HW; ++p) {
+        const int f = pix_to_face[p];
+        if (f < 0) {
+            rgb[p] = 1.f; rgb[HW + p] = 1.f; rgb[2 * HW + p] = 1.f; mask[p] = 0.f;
+            continue;
+        }
+        const float b0 = bary[3 * p], b1 = bary[3 * p + 1], b2 = bary[3 * p + 2];
+        const int u0 = faces_uvs[3 * f], u1 = faces_uvs[3 * f + 1], u2 = faces_uvs[3 * f + 2];
+        const float u = b0 * verts_uvs[2 * u0] + b1 * verts_uvs[2 * u1] + b2 * verts_uvs[2 * u2];
+        const float v = b0 * verts_uvs[2 * u0 + 1] + b1 * verts_uvs[2 * u1 + 1] + b2 * verts_uvs[2 * u2 + 1];
+        bilerp_t q; float ix, iy; int cx, cy;
+        uv_footprint(u, v, T, &q, &ix, &iy, &cx, &cy);
+        float prob, wnum, delta, denom;
+        blend_k1(dists[p], zbuf[p], &prob, &wnum, &delta, &denom);
+        for (int c = 0; c < 3; ++c) {
+            float t = 0.f;
+            if (q.vy0 && q.vx0) t += texture[((size_t)q.r0 * T + q.x0) * 3 + c] * (q.wx0 * q.wy0);
+            if (q.vy0 && q.vx1) t += texture[((size_t)q.r0 * T + q.x1) * 3 + c] * (q.wx1 * q.wy0);
+            if (q.vy1 && q.vx0) t += texture[((size_t)q.r1 * T + q.x0) * 3 + c] * (q.wx0 * q.wy1);
+            if (q.vy1 && q.vx1) t += texture[((size_t)q.r1 * T + q.x1) * 3 + c] * (q.wx1 * q.wy1);
+            rgb[c * HW + p] = (wnum * t + delta * 1.0f) / denom;
+        }
+        mask[p] = ((1.0f - (1.0f - prob)) > 0.f) ? 1.f : 0.f;
+    }
+}
+
+/*
+ * Backward of ref_shade_fwd w.r.t. the texture map (double accumulation, then cast):
+ * grad_rgb (3,S,S) -> grad_texture (T,T,3) ACCUMULATED (+=) so several views can be summed.
+ * Optionally (grad_uv != NULL) also d loss / d (u,v) per pixel (S,S,2) for the vertex path
+ * (bilinear derivative, zero where the coordinate was clamped by padding_mode='border').
+ */
+void ref_shade_bwd(const float *grad_rgb, const int32_t *pix_to_face, const float *bary, const float *zbuf,
+                   const float *dists, const float *verts_uvs, const int32_t *faces_uvs,
+                   const float *texture, int S, int T, double *grad_texture, float *grad_uv)
+{
+    const size_t HW = (size_t)S * S;
+    for (size_t p = 0; p < HW; ++p) {
+        const int f = pix_to_face[p];
+        if (grad_uv) { grad_uv[2 * p] = 0.f; grad_uv[2 * p + 1] = 0.f; }
+        if (f < 0) continue;
+        const float b0 = bary[3 * p], b1 = bary[3 * p + 1], b2 = bary[3 * p + 2];
+        const int u0 = faces_uvs[3 * f], u1 = faces_uvs[3 * f + 1], u2 = faces_uvs[3 * f + 2];
+        const float u = b0 * verts_uvs[2 * u0] + b1 * verts_uvs[2 * u1] + b2 * verts_uvs[2 * u2];
+        const float v = b0 * verts_uvs[2 * u0 + 1] + b1 * verts_uvs[2 * u1 + 1] + b2 * verts_uvs[2 * u2 + 1];
+        bilerp_t q; float ix, iy; int cx, cy;
+        uv_footprint(u, v, T, &q, &ix, &iy, &cx, &cy);
+        float prob, wnum, delta, denom;
+        blend_k1(dists[p], zbuf[p], &prob, &wnum, &delta, &denom);
+        const float k = wnum / denom;                  /* d rgb / d texel */
+        double gix = 0.0, giy = 0.0;
+        for (int c = 0; c < 3; ++c) {
+            const float g = grad_rgb[c * HW + p] * k;
+            float t00 = 0.f, t01 = 0.f, t10 = 0.f, t11 = 0.f;
+            if (q.vy0 && q.vx0) { grad_texture[((size_t)q.r0 * T + q.x0) * 3 + c] += (double)(g * (q.wx0 * q.wy0)); t00 = texture[((size_t)q.r0 * T + q.x0) * 3 + c]; }
+            if (q.vy0 && q.vx1) { grad_texture[((size_t)q.r0 * T + q.x1) * 3 + c] += (double)(g * (q.wx1 * q.wy0)); t01 = texture[((size_t)q.r0 * T + q.x1) * 3 + c]; }
+            if (q.vy1 && q.vx0) { grad_texture[((size_t)q.r1 * T + q.x0) * 3 + c] += (double)(g * (q.wx0 * q.wy1)); t10 = texture[((size_t)q.r1 * T + q.x0) * 3 + c]; }
+            if (q.vy1 && q.vx1) { grad_texture[((size_t)q.r1 * T + q.x1) * 3 + c] += (double)(g * (q.wx1 * q.wy1)); t11 = texture[((size_t)q.r1 * T + q.x1) * 3 + c]; }
+            /* d sample / d ix, d sample / d iy (flipped-map coordinates) */
+            gix += (double)g * ((double)(t01 - t00) * q.wy0 + (double)(t11 - t10) * q.wy1);
+            giy += (double)g * ((double)(t10 - t00) * q.wx0 + (double)(t11 - t01) * q.wx1);
+        }
+        if (grad_uv) {
+            /* ix = u*(T-1); iy_flipped = v*(T-1) */
+            grad_uv[2 * p]     = cx ? 0.f : (float)(gix * (double)(T - 1));
+            grad_uv[2 * p + 1] = cy ? 0.f : (float)(giy * (double)(T - 1));
+        }
+    }
+}
+
+/* ---------------------------------------------------------------- Adam (torch.optim.Adam, utils.py:185-195) */
+
+/* One dense Adam step with torch defaults (amsgrad=False, weight_decay=0, maximize=False):
+ *   m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g ;
+ *   p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps),  bc_i = 1 - b_i^step. */
+void ref_adam_step(float *p, const float *g, float *m, float *v, size_t n, int step,
+                   float lr, float b1, float b2, float eps)
+{
+    const double bc1 = 1.0 - pow((double)b1, (double)step);
+    const double bc2 = 1.0 - pow((double)b2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    for (size_t i = 0; i < n; ++i) {
+        const float gi = g[i];
+        m[i] = m[i] + (gi - m[i]) * (1.0f - b1);          /* torch: exp_avg.lerp_(grad, 1-beta1) */
+        v[i] = v[i] * b2 + (1.0f - b2) * gi * gi;        /* mul_(beta2).addcmul_(g, g, 1-beta2) */
+        const float denom = sqrtf(v[i]) / bc2_sqrt + eps;
+        p[i] = p[i] - step_size * (m[i] / denom);
+    }
+}

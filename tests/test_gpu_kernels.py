@@ -1,0 +1,258 @@
+"""GPU parity tests of every libst3d kernel against the CPU oracle (oracle/) or a plain
+PyTorch fp32 reference of the same op, all through the C ABI.  Tolerances are stated per test.
+
+fp32 MFMA sums in a different order than MKL/oneDNN; for a K-term dot product of O(1) terms the
+two fp32 results differ by ~1e-7*sqrt(K)*|terms|, so contractions are checked at rtol 2e-4 of
+the output scale (an fp64 reference is used to judge both)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from st3d import ops as o
+    return o
+
+
+def _cams(n, seed=0):
+    from oracle import render_ref as rr
+    g = torch.Generator().manual_seed(seed)
+    elev, azim = rr.random_camera_angles(n, lambda k: torch.rand(k, generator=g).numpy())
+    return rr.look_at_view_transform(2.10, elev, azim, at=(0, 0.10, 0.25))
+
+
+def _scale_close(got, ref, rtol, name=""):
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    scale = ref.abs().max().item() + 1e-30
+    err = (got - ref).abs().max().item()
+    assert err <= rtol * scale, f"{name}: max err {err:.3e} > {rtol:.1e} * scale {scale:.3e}"
+
+
+# ---------------------------------------------------------------------------- render
+@pytest.mark.parametrize("S", [64, 200])
+def test_raster_matches_oracle(dev, ops, cow, S):
+    """pix_to_face bit-exact; zbuf/bary/dists bit-exact (both sides built without FMA contraction)."""
+    from oracle import render_ref as rr
+    R, T = _cams(3, seed=S)
+    verts = torch.from_numpy(cow["verts"]).to(dev)
+    faces = torch.from_numpy(cow["faces"]).to(dev)
+    ndc = ops.project_verts(verts, torch.from_numpy(R).to(dev), torch.from_numpy(T).to(dev))
+    p2f, zbuf, bary, dists = ops.raster_fwd(ndc, faces, S)
+    torch.cuda.synchronize()
+    for b in range(3):
+        ndc_ref = rr.project_verts(cow["verts"], R[b], T[b])
+        np.testing.assert_allclose(ndc[b].cpu().numpy(), ndc_ref, rtol=0, atol=0)
+        rp, rz, rb, rd = rr.rasterize(ndc_ref, cow["faces"], S, 0.0, nthreads=8)
+        assert (rp >= 0).sum() > 0.05 * S * S
+        np.testing.assert_array_equal(p2f[b].cpu().numpy(), rp)
+        np.testing.assert_array_equal(zbuf[b].cpu().numpy(), rz)
+        np.testing.assert_array_equal(bary[b].cpu().numpy(), rb)
+        np.testing.assert_array_equal(dists[b].cpu().numpy(), rd)
+
+
+def test_shade_fwd_bwd_match_oracle(dev, ops, cow):
+    """RGB within 2e-6 abs (expf differs by ulps between glibc and the device); texture gradient
+    within 1e-5 of the fp64-accumulated oracle relative to its max (float atomics, any order)."""
+    from oracle import render_ref as rr
+    S, T = 96, 64
+    R, Tt = _cams(2, seed=5)
+    rng = np.random.default_rng(0)
+    tex = rng.random((T, T, 3), dtype=np.float32)
+    imgs_ref, masks_ref, frags = rr.render_views(cow["verts"], cow["faces"], cow["verts_uvs"], cow["faces_uvs"], tex, R,
+                                                 Tt, S, nthreads=8)
+    verts = torch.from_numpy(cow["verts"]).to(dev)
+    faces = torch.from_numpy(cow["faces"]).to(dev)
+    uvs = torch.from_numpy(cow["verts_uvs"]).to(dev)
+    fuv = torch.from_numpy(cow["faces_uvs"]).to(dev)
+    texd = torch.from_numpy(tex).to(dev)
+    ndc = ops.project_verts(verts, torch.from_numpy(R).to(dev), torch.from_numpy(Tt).to(dev))
+    frag = ops.raster_fwd(ndc, faces, S)
+    rgb, mask = ops.shade_fwd(frag, uvs, fuv, texd)
+    np.testing.assert_allclose(rgb.cpu().numpy(), imgs_ref, rtol=0, atol=2e-6)
+    np.testing.assert_array_equal(mask.cpu().numpy(), masks_ref)
+    g = rng.standard_normal((2, 3, S, S)).astype(np.float32)
+    gt_ref = np.zeros((T, T, 3), np.float64)
+    guv_ref = []
+    for b in range(2):
+        _, guv = rr.shade_bwd(g[b], frags[b], cow["verts_uvs"], cow["faces_uvs"], tex, gt_ref, want_uv=True)
+        guv_ref.append(guv)
+    gt, guv = ops.shade_bwd(torch.from_numpy(g).to(dev), frag, uvs, fuv, texd, want_uv=True)
+    _scale_close(gt, torch.from_numpy(gt_ref), 1e-5, "grad_texture")
+    _scale_close(guv, torch.from_numpy(np.stack(guv_ref)), 1e-4, "grad_uv")
+
+
+def test_apply_background(dev, ops):
+    torch.manual_seed(0)
+    img = torch.rand(2, 3, 40, 40, device=dev)
+    m = (torch.rand(2, 1, 40, 40, device=dev) > 0.5).float()
+    bg = torch.rand(2, 3, 40, 40, device=dev)
+    torch.testing.assert_close(ops.apply_background(img, m, bg), img * m + bg * (1 - m), rtol=0, atol=0)
+    torch.testing.assert_close(ops.apply_background(img, m, bg[:1]), img * m + bg[:1] * (1 - m), rtol=0, atol=0)
+
+
+# ---------------------------------------------------------------------------- conv / pool
+CONV_CASES = [(2, 3, 64, 64, 64), (1, 64, 64, 48, 40), (2, 64, 128, 32, 32), (1, 128, 256, 24, 56),
+              (1, 256, 256, 32, 32), (2, 512, 512, 16, 16), (1, 512, 512, 4, 4), (1, 3, 64, 33, 70)]
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W", CONV_CASES)
+def test_conv3x3_fwd(dev, ops, N, Cin, Cout, H, W):
+    torch.manual_seed(Cin * 7 + Cout)
+    x = torch.randn(N, Cin, H, W)
+    w = torch.randn(Cout, Cin, 3, 3) * (2.0 / (Cin * 9)) ** 0.5
+    b = torch.randn(Cout) * 0.1
+    ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1))
+    wf, _ = ops.conv3x3_pack(w.to(dev))
+    y = ops.conv3x3_fwd(x.to(dev), wf, b.to(dev), Cout, relu=True)
+    _scale_close(y, ref, 2e-5, "conv fwd")
+    y2 = ops.conv3x3_fwd(x.to(dev), wf, b.to(dev), Cout, relu=False)
+    _scale_close(y2, F.conv2d(x.double(), w.double(), b.double(), padding=1), 2e-5, "conv fwd (no relu)")
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W", CONV_CASES)
+def test_conv3x3_dgrad(dev, ops, N, Cin, Cout, H, W):
+    """gx = d/dx of sum(gy * relu(conv(x))) -- the ReLU gate is fused into the kernel's load."""
+    torch.manual_seed(Cin * 3 + Cout)
+    x = torch.randn(N, Cin, H, W, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(Cout, Cin, 3, 3) * (2.0 / (Cin * 9)) ** 0.5).double()
+    b = (torch.randn(Cout) * 0.1).double()
+    y = F.relu(F.conv2d(x, w, b, padding=1))
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    _, wd = ops.conv3x3_pack(w.float().to(dev))
+    gx = ops.conv3x3_dgrad(gy.float().to(dev), y.detach().float().to(dev), wd, Cin)
+    _scale_close(gx, x.grad, 2e-5, "conv dgrad")
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 64, 64, 32, 64), (1, 128, 128, 16, 16), (1, 256, 256, 8, 40)])
+def test_conv3x3_dgrad_unpool(dev, ops, N, Cin, Cout, H, W):
+    """gradient through conv -> ReLU -> MaxPool2d(2,2) in one kernel (unpool + gate fused)."""
+    torch.manual_seed(H + W)
+    x = torch.randn(N, Cin, H, W, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(Cout, Cin, 3, 3) * (2.0 / (Cin * 9)) ** 0.5).double()
+    b = (torch.randn(Cout) * 0.1).double()
+    y = F.relu(F.conv2d(x, w, b, padding=1))
+    p = F.max_pool2d(y, 2, 2)
+    gp = torch.randn_like(p)
+    p.backward(gp)
+    wf, wd = ops.conv3x3_pack(w.float().to(dev))
+    yd = ops.conv3x3_fwd(x.detach().float().to(dev), wf, b.float().to(dev), Cout, relu=True)
+    pd, idx = ops.maxpool2x2(yd)
+    _scale_close(pd, p, 2e-5, "pool")
+    gx = ops.conv3x3_dgrad_unpool(gp.float().to(dev), idx, pd, wd, Cin)
+    _scale_close(gx, x.grad, 5e-5, "dgrad_unpool")
+
+
+def test_maxpool_matches_torch(dev, ops):
+    torch.manual_seed(0)
+    y = torch.randn(2, 5, 12, 20)
+    y[0, 0, 0:2, 0:2] = 0.0                                   # tie: the first element wins
+    ref, ridx = F.max_pool2d(y, 2, 2, return_indices=True)
+    p, idx = ops.maxpool2x2(y.to(dev))
+    torch.testing.assert_close(p.cpu(), ref, rtol=0, atol=0)
+    W = 20
+    rr_, cc_ = ridx // W, ridx % W
+    local = (rr_ % 2) * 2 + (cc_ % 2)
+    np.testing.assert_array_equal(idx.cpu().numpy(), local.numpy().astype(np.uint8))
+
+
+# ---------------------------------------------------------------------------- gram / losses / adam
+@pytest.mark.parametrize("B,C,H,W", [(2, 64, 64, 64), (1, 128, 40, 40), (2, 256, 16, 16), (1, 512, 8, 8), (2, 512, 4, 4),
+                                     (1, 64, 3, 3)])
+def test_gram_fwd_bwd(dev, ops, B, C, H, W):
+    torch.manual_seed(C + H)
+    f = torch.rand(B, C, H, W)
+    fd = f.double().reshape(B, C, H * W)
+    ref = torch.bmm(fd, fd.transpose(1, 2))
+    g = ops.gram_fwd(f.to(dev))
+    _scale_close(g, ref, 2e-5, "gram")
+    assert torch.equal(g, g.transpose(1, 2)), "mirrored tiles must make the Gram exactly symmetric"
+    D = torch.randn(B, C, C)
+    D = D + D.transpose(1, 2)
+    refb = 0.37 * torch.bmm(D.double(), fd).reshape(B, C, H, W)
+    out = ops.gram_bwd(D.to(dev), f.to(dev), 0.37)
+    _scale_close(out, refb, 2e-5, "gram bwd")
+    base = torch.randn(B, C, H, W)
+    out2 = ops.gram_bwd(D.to(dev), f.to(dev), 0.37, out=base.clone().to(dev))
+    _scale_close(out2, refb + base.double(), 2e-5, "gram bwd accumulate")
+
+
+def test_gram_golden_g1(dev, ops, golden_dir):
+    """Golden vector produced by the reference's own gram_matrix (style_transfer.py:31-35)."""
+    d = np.load(os.path.join(golden_dir, "g1_gram.npz"))
+    g = ops.gram_fwd(torch.from_numpy(d["x"]).to(dev))
+    np.testing.assert_allclose(g.cpu().numpy(), d["gram"], rtol=1e-5, atol=1e-5)
+
+
+def test_sqdiff_and_masked_mse(dev, ops):
+    torch.manual_seed(0)
+    a, b = torch.randn(3, 1000), torch.randn(1, 1000)
+    out, D = ops.sqdiff_sum(a.to(dev), b.to(dev), scale=0.5, want_diff=True)
+    ref = 0.5 * ((a.double() - b.double()) ** 2).sum()
+    assert abs(out.item() - ref.item()) <= 1e-5 * abs(ref.item())
+    torch.testing.assert_close(D.cpu(), a - b, rtol=0, atol=0)
+    r = torch.rand(2, 3, 24, 24, dtype=torch.float64, requires_grad=True)
+    t = torch.rand(2, 3, 24, 24, dtype=torch.float64)
+    m = (torch.rand(2, 1, 24, 24) > 0.4).double()
+    loss = F.mse_loss(r * m, t * m)
+    loss.backward()
+    out, g = ops.masked_mse(r.detach().float().to(dev), t.float().to(dev), m.float().to(dev))
+    assert abs(out.item() - loss.item()) <= 1e-5 * loss.item()
+    _scale_close(g, r.grad, 1e-5, "masked mse grad")
+
+
+def test_adam_matches_torch_optim(dev, ops):
+    """Five steps of the fused Adam vs torch.optim.Adam (the optimiser the reference uses)."""
+    torch.manual_seed(0)
+    p0 = torch.randn(5000)
+    grads = [torch.randn(5000) * (0.1 + i) for i in range(5)]
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=0.01)
+    p = p0.clone().to(dev)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for i, g in enumerate(grads):
+        pr.grad = g.clone()
+        opt.step()
+        ops.adam_step(p, g.to(dev), m, v, i + 1, 0.01)
+    torch.testing.assert_close(p.cpu(), pr.detach(), rtol=1e-5, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------- fused plan vs the reference's golden vectors
+def test_plan_matches_reference_golden_g3(dev, golden_dir):
+    """compute_perceptual_loss value + gradient produced by the reference's losses.py on the
+    seeded VGG (tests/golden/make_golden.py).  Loss within 2e-4 relative, gradient within 1e-3
+    relative L2 (fp32, different summation order over K up to 4608 and Gram K = 4096)."""
+    from st3d import vgg as V
+    d = np.load(os.path.join(golden_dir, "g3_perceptual.npz"))
+    model = V.Vgg19Features(V.synthetic_state(0), device=dev)
+    plan = model.plan(2, 64)
+    cur, con, sty = (torch.from_numpy(d[k]).to(dev) for k in ("cur", "con", "sty"))
+    plan.set_content(con)
+    plan.set_style(sty, 2)
+    loss, grad = plan.loss(cur, 1e6, 1.0)
+    torch.cuda.synchronize()
+    total = loss[0].item()
+    assert abs(total - float(d["loss"])) <= 2e-4 * float(d["loss"]), (total, float(d["loss"]))
+    gref = torch.from_numpy(d["grad"])
+    rel = (grad.cpu() - gref).norm().item() / gref.norm().item()
+    assert rel <= 1e-3, rel
+    # features / Grams of the current images against the reference's get_features / gram_matrix
+    plan.forward(cur, upto=28)
+    f5 = plan.activation(28).cpu().numpy()
+    np.testing.assert_allclose(f5, d["feat_conv5_1"], rtol=2e-4, atol=2e-4 * np.abs(d["feat_conv5_1"]).max())
+    f1 = plan.activation(0).cpu()
+    assert float(f1.min()) == 0.0                                   # taps are post-ReLU
+    np.testing.assert_allclose(f1[0, 0].numpy(), d["feat_conv1_1_img0_ch0"], rtol=1e-5, atol=1e-5)
