@@ -1,0 +1,300 @@
+"""Scene containers, cameras and the differentiable renderer on libst3d.
+
+Host-side mirror of the PyTorch3D objects the reference builds (first_approach.py:104-113,
+second_approach.py:98-108, utils.py:6-9,121-170,207-210): thin structs with the same
+constructor arguments and accessor names, so the drop-in ``utils.py`` / approach scripts read
+like the reference.  Rendering itself is NOT a per-camera Python loop of ~20 small launches as
+upstream: all views of a batch go through four HIP launches (project, face setup + tile
+raster, fused shade) and the backward is one launch (texture scatter).
+
+Only what the reference configures is implemented: blur_radius=0, faces_per_pixel=1,
+AmbientLights, FoV perspective cameras with default fov/znear/zfar.
+"""
+import math
+
+import torch
+
+from . import ops
+
+# ------------------------------------------------------------------------ containers
+
+_I32_CACHE = {}
+
+
+def _checked_i32(idx, limit, what):
+    """int64 index tensor -> validated contiguous int32 copy, cached on the tensor's identity:
+    the reference rebuilds its Meshes every step (second_approach.py:164) from the SAME index
+    tensors, and the range check costs a host sync, so it must not be repeated per step.
+    (An out-of-range index would fault the GPU inside the raster/shade kernels.)"""
+    key = (idx.data_ptr(), tuple(idx.shape), idx._version, int(limit), str(idx.device))
+    hit = _I32_CACHE.get(key)
+    if hit is None:
+        if idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= limit):
+            raise ValueError(f"{what} holds indices outside [0, {limit})")
+        if len(_I32_CACHE) > 64:
+            _I32_CACHE.clear()
+        hit = (idx.to(torch.int32).contiguous(), idx)        # keep the source alive: data_ptr stays unique
+        _I32_CACHE[key] = hit
+    return hit[0]
+
+
+
+class TexturesUV:
+    """utils.py:208 ``TexturesUV(verts_uvs=..., faces_uvs=..., maps=...)``; maps (1,T,T,3)."""
+
+    def __init__(self, maps, faces_uvs, verts_uvs):
+        if isinstance(maps, (list, tuple)):
+            maps = torch.stack(list(maps))
+        if isinstance(verts_uvs, (list, tuple)):
+            verts_uvs = torch.stack(list(verts_uvs))
+        if isinstance(faces_uvs, (list, tuple)):
+            faces_uvs = torch.stack(list(faces_uvs))
+        self._maps = maps if maps.dim() == 4 else maps[None]
+        self._verts_uvs = verts_uvs if verts_uvs.dim() == 3 else verts_uvs[None]
+        self._faces_uvs = faces_uvs if faces_uvs.dim() == 3 else faces_uvs[None]
+        self._faces_uvs_i32 = None
+
+    def maps_padded(self):
+        return self._maps
+
+    def verts_uvs_padded(self):
+        return self._verts_uvs
+
+    def faces_uvs_padded(self):
+        return self._faces_uvs
+
+    def faces_uvs_i32(self):
+        if self._faces_uvs_i32 is None:
+            self._faces_uvs_i32 = _checked_i32(self._faces_uvs[0], self._verts_uvs.shape[1], "faces_uvs")
+        return self._faces_uvs_i32
+
+    def clone(self):
+        t = TexturesUV(self._maps.clone(), self._faces_uvs.clone(), self._verts_uvs.clone())
+        return t
+
+    def detach(self):
+        return TexturesUV(self._maps.detach(), self._faces_uvs, self._verts_uvs.detach())
+
+
+class Meshes:
+    """utils.py:209 ``Meshes(verts=[verts], faces=[faces], textures=textures)`` (one mesh)."""
+
+    def __init__(self, verts, faces, textures=None):
+        if isinstance(verts, (list, tuple)):
+            assert len(verts) == 1, "one mesh per batch (the reference never batches meshes)"
+            verts = verts[0]
+        if isinstance(faces, (list, tuple)):
+            faces = faces[0]
+        if verts.dim() == 3:
+            assert verts.shape[0] == 1
+            self._verts_padded = verts
+            self._verts = None
+        else:
+            self._verts = verts
+            self._verts_padded = None
+        self._faces = faces[0] if faces.dim() == 3 else faces
+        self.textures = textures
+        self._faces_i32 = None
+
+    def verts_packed(self):
+        if self._verts is None:
+            self._verts = self._verts_padded[0]
+        return self._verts
+
+    def verts_padded(self):
+        if self._verts_padded is None:
+            self._verts_padded = self._verts[None]
+        return self._verts_padded
+
+    def faces_packed(self):
+        return self._faces
+
+    def faces_padded(self):
+        return self._faces[None]
+
+    def faces_i32(self):
+        if self._faces_i32 is None:
+            self._faces_i32 = _checked_i32(self._faces, self.verts_packed().shape[0], "faces")
+        return self._faces_i32
+
+    def clone(self):
+        return Meshes(self.verts_packed().clone(), self._faces.clone(),
+                      self.textures.clone() if self.textures is not None else None)
+
+    def detach(self):
+        return Meshes(self.verts_packed().detach(), self._faces,
+                      self.textures.detach() if self.textures is not None else None)
+
+    @property
+    def device(self):
+        return self.verts_packed().device
+
+
+# ------------------------------------------------------------------------ cameras
+
+
+class FoVPerspectiveCameras:
+    """R (n,3,3), T (n,3) in the row-vector convention X_view = X_world R + T; defaults
+    fov=60 deg, znear=1, zfar=100, aspect=1 (the reference never overrides them)."""
+
+    def __init__(self, R=None, T=None, device="cpu", fov=60.0, znear=1.0, zfar=100.0):
+        dev = torch.device(device)
+        self.R = (torch.eye(3)[None] if R is None else R).to(dev, torch.float32).reshape(-1, 3, 3)
+        self.T = (torch.zeros(1, 3) if T is None else T).to(dev, torch.float32).reshape(-1, 3)
+        if (fov, znear, zfar) != (60.0, 1.0, 100.0):
+            raise NotImplementedError("only the FoVPerspectiveCameras defaults the reference uses are supported")
+        self.device = dev
+
+    def __len__(self):
+        return self.R.shape[0]
+
+    def __getitem__(self, i):
+        if isinstance(i, int):
+            i = slice(i, i + 1)
+        return FoVPerspectiveCameras(self.R[i], self.T[i], device=self.device)
+
+
+def join_cameras(cameras):
+    """list of cameras (as utils.py:68 iterates) or one batched camera -> (R (B,3,3), T (B,3))."""
+    if isinstance(cameras, FoVPerspectiveCameras):
+        return cameras.R, cameras.T
+    return torch.cat([c.R for c in cameras], 0), torch.cat([c.T for c in cameras], 0)
+
+
+def look_at_view_transform(dist=1.0, elev=0.0, azim=0.0, at=((0, 0, 0),), up=((0, 1, 0),), device="cpu"):
+    """PyTorch3D look_at_view_transform with degrees=True (utils.py:161-166)."""
+    def _t(x):
+        x = torch.as_tensor(x, dtype=torch.float32)
+        return x.reshape(-1) if x.dim() <= 1 else x
+    dist, elev, azim = _t(dist), _t(elev) * (math.pi / 180.0), _t(azim) * (math.pi / 180.0)
+    at = torch.as_tensor(at, dtype=torch.float32).reshape(-1, 3)
+    up = torch.as_tensor(up, dtype=torch.float32).reshape(-1, 3)
+    n = max(dist.numel(), elev.numel(), azim.numel(), at.shape[0])
+    dist, elev, azim = (t.expand(n) for t in (dist, elev, azim))
+    at, up = at.expand(n, 3), up.expand(n, 3)
+    x = dist * torch.cos(elev) * torch.sin(azim)
+    y = dist * torch.sin(elev)
+    z = dist * torch.cos(elev) * torch.cos(azim)
+    C = torch.stack([x, y, z], dim=1) + at
+    z_axis = torch.nn.functional.normalize(at - C, eps=1e-5)
+    x_axis = torch.nn.functional.normalize(torch.cross(up, z_axis, dim=1), eps=1e-5)
+    y_axis = torch.nn.functional.normalize(torch.cross(z_axis, x_axis, dim=1), eps=1e-5)
+    is_close = torch.isclose(x_axis, torch.tensor(0.0), atol=5e-3).all(dim=1, keepdim=True)
+    if is_close.any():
+        repl = torch.nn.functional.normalize(torch.cross(y_axis, z_axis, dim=1), eps=1e-5)
+        x_axis = torch.where(is_close, repl, x_axis)
+    R = torch.cat((x_axis[:, None, :], y_axis[:, None, :], z_axis[:, None, :]), dim=1).transpose(1, 2)
+    T = -torch.bmm(R.transpose(1, 2), C[:, :, None])[:, :, 0]
+    return R.to(device), T.to(device)
+
+
+class RotateAxisAngle:
+    """utils.py:142 ``RotateAxisAngle(angle, axis=axis).get_matrix()[..., :3, :3]``."""
+
+    def __init__(self, angle, axis="X", degrees=True, device="cpu"):
+        a = float(angle) * (math.pi / 180.0 if degrees else 1.0)
+        c, s = math.cos(a), math.sin(a)
+        if axis == "X":
+            m = [[1, 0, 0], [0, c, -s], [0, s, c]]
+        elif axis == "Y":
+            m = [[c, 0, s], [0, 1, 0], [-s, 0, c]]
+        elif axis == "Z":
+            m = [[c, -s, 0], [s, c, 0], [0, 0, 1]]
+        else:
+            raise ValueError("axis must be X, Y or Z")
+        M = torch.eye(4, dtype=torch.float32)
+        M[:3, :3] = torch.tensor(m, dtype=torch.float32).t()     # row-vector convention
+        self._m = M[None].to(device)
+
+    def get_matrix(self):
+        return self._m
+
+
+# ------------------------------------------------------------------------ renderer
+
+
+class RasterizationSettings:
+    def __init__(self, image_size=256, blur_radius=0.0, faces_per_pixel=1, **kw):
+        if blur_radius != 0.0 or faces_per_pixel != 1:
+            raise NotImplementedError("the reference fixes blur_radius=0.0, faces_per_pixel=1 "
+                                      "(first_approach.py:107); the soft rasteriser is a later row")
+        self.image_size, self.blur_radius, self.faces_per_pixel = int(image_size), 0.0, 1
+
+
+class AmbientLights:
+    def __init__(self, ambient_color=((1.0, 1.0, 1.0),), device="cpu"):
+        c = torch.as_tensor(ambient_color, dtype=torch.float32).reshape(-1)
+        if not torch.allclose(c, torch.ones(3)):
+            raise NotImplementedError("only the default white ambient light is supported")
+
+
+class MeshRasterizer:
+    def __init__(self, cameras=None, raster_settings=None):
+        self.cameras, self.raster_settings = cameras, raster_settings or RasterizationSettings()
+
+
+class SoftPhongShader:
+    def __init__(self, device="cpu", cameras=None, lights=None, **kw):
+        self.cameras, self.lights = cameras, lights
+
+
+class _RenderFn(torch.autograd.Function):
+    """(verts, texture_map) -> (rgb (B,3,S,S), mask (B,1,S,S)); backward = texture scatter."""
+
+    @staticmethod
+    def forward(ctx, verts, tex_map, faces_i32, verts_uvs, faces_uvs_i32, R, T, S):
+        v = verts.detach().to(torch.float32).contiguous()
+        tex = tex_map.detach().to(torch.float32).reshape(tex_map.shape[-3], tex_map.shape[-2], 3).contiguous()
+        if tex.shape[0] != tex.shape[1]:
+            raise NotImplementedError("square texture maps only (the reference resizes to size x size)")
+        uvs = verts_uvs.detach().to(torch.float32).reshape(-1, 2).contiguous()
+        ndc = ops.project_verts(v, R, T)
+        frag = ops.raster_fwd(ndc, faces_i32, S)
+        rgb, mask = ops.shade_fwd(frag, uvs, faces_uvs_i32, tex)
+        ctx.frag, ctx.uvs, ctx.fuv, ctx.tex = frag, uvs, faces_uvs_i32, tex
+        ctx.tex_shape = tex_map.shape
+        ctx.verts_need_grad = verts.requires_grad
+        ctx.mark_non_differentiable(mask)
+        return rgb, mask
+
+    @staticmethod
+    def backward(ctx, grad_rgb, _grad_mask):
+        if ctx.verts_need_grad:
+            raise NotImplementedError("vertex gradients (optimization_target 'mesh'/'both') are not built yet: "
+                                      "SURVEY.md 8 row K14; texture optimisation is")
+        gtex = None
+        if ctx.needs_input_grad[1]:
+            gtex = ops.shade_bwd(grad_rgb.to(torch.float32), ctx.frag, ctx.uvs, ctx.fuv, ctx.tex).reshape(ctx.tex_shape)
+        return None, gtex, None, None, None, None, None, None
+
+
+def render_views(meshes, R, T, image_size):
+    """All B views in one batch of launches -> (rgb (B,3,S,S), mask (B,1,S,S))."""
+    tex = meshes.textures
+    dev = meshes.device
+    return _RenderFn.apply(meshes.verts_packed(), tex.maps_padded(), meshes.faces_i32(), tex.verts_uvs_padded(),
+                           tex.faces_uvs_i32(), R.to(dev), T.to(dev), int(image_size))
+
+
+class MeshRenderer:
+    """``renderer(meshes_world=mesh, cameras=camera)`` -> (n,S,S,4) RGBA like PyTorch3D's
+    MeshRenderer (utils.py:69); ``render_meshes`` in the drop-in utils.py calls
+    ``render_views`` directly and skips the RGBA repack."""
+
+    def __init__(self, rasterizer, shader):
+        self.rasterizer, self.shader = rasterizer, shader
+
+    @property
+    def image_size(self):
+        return self.rasterizer.raster_settings.image_size
+
+    def __call__(self, meshes_world, cameras=None, **kw):
+        cameras = cameras if cameras is not None else self.rasterizer.cameras
+        R, T = join_cameras(cameras)
+        rgb, mask = render_views(meshes_world, R, T, self.image_size)
+        # alpha of softmax_rgb_blend with K=1 is in [0.5,1) on covered pixels, 0 elsewhere; only
+        # (alpha > 0) is ever consumed (utils.py:72), so the mask stands in for it
+        return torch.cat([rgb, mask], dim=1).permute(0, 2, 3, 1)
+
+    def to(self, *a, **k):
+        return self
