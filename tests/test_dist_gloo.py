@@ -1,0 +1,79 @@
+"""World-size-2 rehearsal (gloo, CPU) of the view-sharded data parallelism:
+the texture gradient of a B-view step equals the SUM over ranks of the gradients of their view
+slices when every rank divides its loss means by the GLOBAL batch -- the identity the N>1 path of
+bench.py / second_approach.py relies on -- using the package's own shard_views / all_reduce_sum_
+and the CPU oracle for the arithmetic."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "2d-to-3d-style-transfer_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from oracle import perceptual_ref as P
+    from st3d import optim as O
+    r, w, _ = O.init_distributed(backend="gloo")
+    assert (r, w) == (rank, world) and dist.get_backend() == "gloo"
+    B, S = 4, 32
+    g = torch.Generator().manual_seed(0)
+    tex = torch.rand(1, 3, S, S, generator=g)                      # the shared ("replicated") parameter
+    offs = torch.rand(B, 3, S, S, generator=g) * 0.1               # per-view differences
+    content = torch.rand(B, 3, S, S, generator=g)
+    style = torch.rand(1, 3, S, S, generator=g)
+    model = P.make_vgg19_features(seed=0)
+    lo, hi = O.shard_views(B, rank, world)
+    n = hi - lo
+    p = tex.clone().requires_grad_(True)
+    cur = p + offs[lo:hi]
+    # local means are over n views; rescale to the GLOBAL batch (= batch_denom in st3d_plan_loss)
+    loss = P.perceptual_loss_ref(cur, content[lo:hi], style.expand(n, -1, -1, -1), model) * (n / B)
+    loss.backward()
+    grad = p.grad.clone()
+    O.all_reduce_sum_(grad)
+    lt = loss.detach().clone()
+    O.all_reduce_sum_(lt)
+    if rank == 0:
+        pf = tex.clone().requires_grad_(True)
+        full = P.perceptual_loss_ref(pf + offs, content, style.expand(B, -1, -1, -1), model)
+        full.backward()
+        np.savez(os.path.join(out_dir, "res.npz"), grad=grad.numpy(), full_grad=pf.grad.numpy(), loss=float(lt),
+                 full_loss=float(full))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_sum_equals_full_batch(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    d = np.load(tmp_path / "res.npz")
+    assert abs(d["loss"] - d["full_loss"]) <= 1e-5 * abs(d["full_loss"])
+    rel = np.linalg.norm(d["grad"] - d["full_grad"]) / np.linalg.norm(d["full_grad"])
+    assert rel <= 1e-5, rel
+
+
+def test_dist_info_defaults(monkeypatch):
+    from st3d import optim as O
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    assert O.dist_info() == (0, 1, 0)
+    t = torch.ones(3)
+    assert O.all_reduce_sum_(t) is t and torch.equal(t, torch.ones(3))     # no process group: identity

@@ -1,0 +1,301 @@
+"""GPU parity tests at the drop-in API level: the reference's function surface
+(style_transfer.py / losses.py / utils.py / the two CLIs) running on libst3d, checked against the
+golden vectors produced by the reference's own code, against the CPU oracle, and -- at
+BASELINE.json's full size -- through size-independent properties."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    assert torch.cuda.is_available()
+    import losses as L
+    import style_transfer as ST
+    import utils as U
+    dev = torch.device("cuda:0")
+    U.device = ST.device = L.device = dev
+    return ST, L, U, dev
+
+
+@pytest.fixture(scope="module")
+def vgg(mods):
+    _, _, U, _ = mods
+    return U.get_vgg(seed=0)
+
+
+@pytest.fixture(scope="module")
+def scene(mods, cow):
+    _, _, U, dev = mods
+    from st3d.render import FoVPerspectiveCameras, MeshRasterizer, MeshRenderer, RasterizationSettings, SoftPhongShader
+
+    def make(S, T, B, seed=0):
+        rng = np.random.default_rng(seed)
+        tex_np = rng.random((T, T, 3), dtype=np.float32)
+        from oracle import render_ref as rr
+        g = torch.Generator().manual_seed(seed)
+        elev, azim = rr.random_camera_angles(B, lambda k: torch.rand(k, generator=g).numpy())
+        R, Tt = rr.look_at_view_transform(2.10, elev, azim, at=(0, 0.10, 0.25))
+        mesh = U.build_mesh(torch.from_numpy(cow["verts_uvs"])[None].to(dev),
+                            torch.from_numpy(cow["faces_uvs"].astype(np.int64))[None].to(dev),
+                            torch.from_numpy(tex_np)[None].to(dev), torch.from_numpy(cow["verts"]).to(dev),
+                            torch.from_numpy(cow["faces"].astype(np.int64)).to(dev))
+        renderer = MeshRenderer(MeshRasterizer(None, RasterizationSettings(image_size=S)), SoftPhongShader())
+        cams = FoVPerspectiveCameras(R=torch.from_numpy(R), T=torch.from_numpy(Tt), device=dev)
+        return mesh, renderer, cams, tex_np, R, Tt
+    return make
+
+
+def test_get_features_fused_equals_generic_walk_and_oracle(mods, vgg, golden_dir):
+    ST, _, _, dev = mods
+    from oracle import perceptual_ref as P
+    d = np.load(os.path.join(golden_dir, "g3_perceptual.npz"))
+    x = torch.from_numpy(d["cur"]).to(dev)
+    fused = ST.get_features(x, vgg)
+    assert list(fused) == ["conv1_1", "conv2_1", "conv3_1", "conv4_1", "conv4_2", "conv5_1"]
+
+    class Walk:                     # same modules, but not recognised -> the reference's generic loop
+        _modules = vgg._modules
+    generic = ST.get_features(x.clone(), Walk)
+    ref = P.get_features_ref(torch.from_numpy(d["cur"]), P.make_vgg19_features(seed=0))
+    for k in fused:
+        assert float(fused[k].min()) == 0.0
+        torch.testing.assert_close(fused[k], generic[k], rtol=0, atol=0)       # same kernels, same bits
+        scale = float(ref[k].abs().max())
+        assert float((fused[k].cpu() - ref[k]).abs().max()) <= 2e-4 * scale
+    # custom layer dict incl. a pool output and the unused tail (module 36)
+    f2 = ST.get_features(x, vgg, layers={"4": "pool1", "36": "pool5"})
+    assert f2["pool1"].shape == (2, 64, 32, 32) and f2["pool5"].shape == (2, 512, 2, 2)
+
+
+def test_gram_matrix_autograd(mods):
+    ST, _, _, dev = mods
+    torch.manual_seed(0)
+    t = torch.rand(2, 64, 16, 16, device=dev, requires_grad=True)
+    g = ST.gram_matrix(t)
+    w = torch.randn_like(g)
+    (g * w).sum().backward()
+    td = t.detach().double().cpu().requires_grad_(True)
+    f = td.reshape(2, 64, 256)
+    gr = torch.bmm(f, f.transpose(1, 2))
+    (gr * w.double().cpu()).sum().backward()
+    assert float((g.detach().cpu().double() - gr.detach()).abs().max()) <= 2e-5 * float(gr.abs().max())
+    assert float((t.grad.cpu().double() - td.grad).abs().max()) <= 2e-5 * float(td.grad.abs().max())
+
+
+@pytest.mark.parametrize("fixture,B,S", [("g3_perceptual.npz", 2, 64), ("g3b_perceptual_96.npz", 1, 96)])
+def test_compute_perceptual_loss_matches_reference_golden(mods, vgg, golden_dir, fixture, B, S):
+    """loss within 2e-4 relative, d loss/d current within 1e-3 relative L2 of the reference's
+    losses.compute_perceptual_loss + autograd (fp32, different summation order)."""
+    _, L, _, dev = mods
+    d = np.load(os.path.join(golden_dir, fixture))
+    cur = torch.from_numpy(d["cur"]).to(dev).requires_grad_(True)
+    kw = {}
+    if "style_weight" in d.files:
+        kw = {"style_weight": float(d["style_weight"]), "content_weight": float(d["content_weight"])}
+    loss = L.compute_perceptual_loss(cur, torch.from_numpy(d["con"]).to(dev), torch.from_numpy(d["sty"]).to(dev), vgg, **kw)
+    loss.backward()
+    assert abs(loss.item() - float(d["loss"])) <= 2e-4 * float(d["loss"])
+    gref = torch.from_numpy(d["grad"])
+    assert float((cur.grad.cpu() - gref).norm() / gref.norm()) <= 1e-3
+    # the 'texture' branch of compute_second_approach_loss is the same number (losses.py:103-104)
+    l2 = L.compute_second_approach_loss(cur.detach(), torch.from_numpy(d["con"]).to(dev), torch.from_numpy(d["sty"]).to(dev),
+                                        vgg, kw.get("style_weight", 1e6), kw.get("content_weight", 1), None, None, None, {},
+                                        "texture")
+    assert l2.item() == loss.item()
+    with pytest.raises(AssertionError):
+        L.compute_perceptual_loss(cur[:1], torch.from_numpy(d["con"]).to(dev).repeat(2, 1, 1, 1)[:3],
+                                  torch.from_numpy(d["sty"]).to(dev), vgg)
+
+
+def test_first_approach_loss_matches_reference_golden(mods, golden_dir):
+    _, L, _, dev = mods
+    d = np.load(os.path.join(golden_dir, "g3_perceptual.npz"))
+    r = torch.from_numpy(d["cur"]).to(dev).requires_grad_(True)
+    loss = L.compute_first_approach_loss(r, torch.from_numpy(d["masks"]).to(dev), torch.from_numpy(d["con"]).to(dev), None,
+                                         None, None, {}, "texture")
+    loss.backward()
+    assert abs(loss.item() - float(d["first_loss"])) <= 1e-6
+    rc = torch.from_numpy(d["cur"]).requires_grad_(True)
+    m = torch.from_numpy(d["masks"])
+    torch.nn.functional.mse_loss(rc * m, torch.from_numpy(d["con"]) * m).backward()
+    torch.testing.assert_close(r.grad.cpu(), rc.grad, rtol=1e-5, atol=1e-9)
+
+
+def test_style_transfer_matches_reference_trajectory(mods, vgg, golden_dir):
+    """Six steps of the reference's style_transfer() (golden G4): final pixels within 5e-4 abs
+    (Adam's m/sqrt(v) normalisation amplifies tiny gradient differences in the first steps)."""
+    ST, _, _, dev = mods
+    d = np.load(os.path.join(golden_dir, "g4_style_transfer.npz"))
+    res = ST.style_transfer(torch.from_numpy(d["init"]).to(dev), torch.from_numpy(d["con"]).to(dev),
+                            torch.from_numpy(d["sty"]).to(dev), vgg, steps=int(d["steps"]), style_weight=1e6,
+                            content_weight=1, lr=float(d["lr"]))
+    assert res.requires_grad and res.is_leaf
+    err = (res.detach().cpu() - torch.from_numpy(d["result"])).abs()
+    assert float(err.max()) <= 5e-4, float(err.max())
+    moved = (torch.from_numpy(d["result"]) - torch.from_numpy(d["init"])).abs().mean()
+    assert float(err.mean()) <= 0.01 * float(moved)
+
+
+def test_render_meshes_pixels_and_texture_gradient_match_oracle(mods, vgg, scene, cow):
+    """Rendered pixels within 2e-6 of the CPU restatement; d loss/d texture through render ->
+    VGG -> losses within 2e-3 relative L2 of the oracle's chain."""
+    _, L, U, dev = mods
+    from oracle import perceptual_ref as P
+    from oracle import render_ref as rr
+    S, T, B = 96, 48, 2
+    mesh0, renderer, cams, tex_np, R, Tt = scene(S, T, B, seed=3)
+    out = U.setup_optimizations("texture", mesh0, 0.01)
+    mesh = U.build_mesh(out["verts_uvs"], out["faces_uvs"], out["texture_map"], out["verts"], out["faces"])
+    cur, masks = U.render_meshes(renderer, mesh, [cams[0], cams[1]])          # list of single cameras, as the reference passes
+    assert cur.shape == (B, 3, S, S) and masks.shape == (B, 1, S, S) and cur.requires_grad and not masks.requires_grad
+    imgs, mref, frags = rr.render_views(cow["verts"], cow["faces"], cow["verts_uvs"], cow["faces_uvs"], tex_np, R, Tt, S, 8)
+    np.testing.assert_allclose(cur.detach().cpu().numpy(), imgs, rtol=0, atol=2e-6)
+    np.testing.assert_array_equal(masks.cpu().numpy(), mref)
+    rgba = renderer(meshes_world=mesh, cameras=cams[0])
+    assert rgba.shape == (1, S, S, 4)
+    torch.testing.assert_close(rgba[0, ..., :3].permute(2, 0, 1), cur[0].detach(), rtol=0, atol=0)
+    assert torch.equal((rgba[0, ..., 3] > 0).float(), masks[0, 0])
+    sty = torch.rand(1, 3, S, S, generator=torch.Generator().manual_seed(9))
+    con = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(8))
+    loss = L.compute_perceptual_loss(cur, con.to(dev), sty.to(dev).expand(B, -1, -1, -1), vgg)
+    loss.backward()
+    cur_t = torch.from_numpy(imgs).requires_grad_(True)
+    ref = P.perceptual_loss_ref(cur_t, con, sty.expand(B, -1, -1, -1), P.make_vgg19_features(seed=0))
+    ref.backward()
+    assert abs(loss.item() - ref.item()) <= 2e-4 * abs(ref.item())
+    gref = np.zeros((T, T, 3), np.float64)
+    for b in range(B):
+        rr.shade_bwd(cur_t.grad.numpy()[b], frags[b], cow["verts_uvs"], cow["faces_uvs"], tex_np, gref)
+    g = out["texture_map"].grad[0].cpu().numpy()
+    assert np.linalg.norm(g - gref) <= 2e-3 * np.linalg.norm(gref)
+    # fused Adam through the optimizer object the reference's loop drives
+    before = out["texture_map"].detach().clone()
+    out["optimizer"].step()
+    moved = (out["texture_map"].detach() - before).abs()
+    seen = torch.from_numpy(gref != 0).to(dev)
+    assert float(moved[0][seen].min()) > 0 and float(moved[0][~seen].max()) == 0.0      # unseen texels stay put (notes.txt:12-16)
+    out["optimizer"].zero_grad()
+    assert out["texture_map"].grad is None
+
+
+def test_apply_background_modes(mods):
+    _, _, U, dev = mods
+    torch.manual_seed(0)
+    t = torch.rand(2, 3, 32, 32, device=dev, requires_grad=True)
+    m = (torch.rand(2, 1, 32, 32, device=dev) > 0.5).float()
+    bg = torch.rand(2, 3, 32, 32, device=dev)
+    o = U.apply_background(t, m, "style", bg)
+    torch.testing.assert_close(o.detach(), t.detach() * m + bg * (1 - m), rtol=0, atol=0)
+    o.sum().backward()
+    torch.testing.assert_close(t.grad, m.expand_as(t), rtol=0, atol=0)
+    n = U.apply_background(t.detach(), m, "noise")
+    assert torch.equal(n * m, t.detach() * m) and float(((n - t.detach()).abs() * (1 - m)).sum()) > 0
+
+
+def _write_cow_assets(tmp, cow, golden_dir, tex_size=64):
+    from PIL import Image
+    from st3d import io as stio
+    tex = torch.from_numpy(cow["texture_u8"][::1024 // tex_size, ::1024 // tex_size].copy()).float() / 255
+    obj = os.path.join(tmp, "cow.obj")
+    stio.save_obj(obj, torch.from_numpy(cow["verts"]), torch.from_numpy(cow["faces"].astype(np.int64)),
+                  torch.from_numpy(cow["verts_uvs"]), torch.from_numpy(cow["faces_uvs"].astype(np.int64)), tex)
+    sty = np.load(os.path.join(golden_dir, "assets_style1_512.npz"))["rgb_u8"]
+    style = os.path.join(tmp, "style.png")
+    Image.fromarray(sty).save(style)
+    return obj, style
+
+
+def test_second_approach_cli_end_to_end(mods, cow, golden_dir, tmp_path):
+    """The drop-in CLI (config-1 plumbing at toy size): artefacts, log format, decreasing loss."""
+    import second_approach as SA
+    obj, style = _write_cow_assets(str(tmp_path), cow, golden_dir)
+    outp = str(tmp_path / "out2")
+    SA.main(["--obj_path", obj, "--style_path", style, "--size", "64", "--n_views", "3", "--batch_size", "2",
+             "--epochs", "4", "--output_path", outp, "--seed", "0", "--lr", "0.02"])
+    log = open(os.path.join(outp, "log.txt")).read().splitlines()
+    assert log[0] == "Logger:" and len(log) == 5 and log[1].startswith("Epoch 0, Loss ")
+    losses = [float(line.split("Loss ")[1]) for line in log[1:]]
+    assert losses[-1] < losses[0]
+    assert sorted(os.listdir(os.path.join(outp, "current_images"))) == ["view_0.png", "view_1.png", "view_2.png"]
+    assert len(os.listdir(os.path.join(outp, "final_render"))) == 12
+    for f in ("final.obj", "final.mtl", "final.png"):
+        assert os.path.exists(os.path.join(outp, f))
+
+
+def test_first_approach_cli_end_to_end(mods, cow, golden_dir, tmp_path):
+    import first_approach as FA
+    obj, style = _write_cow_assets(str(tmp_path), cow, golden_dir)
+    outp = str(tmp_path / "out1")
+    FA.main(["--obj_path", obj, "--style_path", style, "--size", "64", "--n_views", "2", "--batch_size", "2",
+             "--n_style_transfer_steps", "5", "--n_mse_steps", "6", "--output_path", outp, "--seed", "0"])
+    log = open(os.path.join(outp, "log.txt")).read().splitlines()
+    assert log[0] == "Logger:" and len(log) == 7 and log[1].startswith("Batch 0, Step 0, Loss ")
+    losses = [float(line.split("Loss ")[1]) for line in log[1:]]
+    assert losses[-1] < losses[0]
+    assert sorted(os.listdir(os.path.join(outp, "2d_style_transfer"))) == ["view_0.png", "view_1.png"]
+    assert os.path.exists(os.path.join(outp, "final.obj"))
+
+
+def test_full_size_properties_config2(mods, vgg, scene):
+    """BASELINE.json configs[1] (512x512, 8 views, 512^2 texture): size-independent properties --
+    the loss is reproducible bit for bit (ordered reductions), batch-linearity of the gradient
+    (grad of 8 views == sum of two 4-view halves at batch_denom 8), adjointness of the texture
+    scatter at full size, and five optimiser steps reduce the loss."""
+    _, L, U, dev = mods
+    S, T, B = 512, 512, 8
+    mesh0, renderer, cams, tex_np, R, Tt = scene(S, T, B, seed=0)
+    out = U.setup_optimizations("texture", mesh0, 0.01)
+    tex = out["texture_map"]
+    sty = torch.rand(1, 3, S, S, generator=torch.Generator().manual_seed(1)).to(dev)
+    with torch.no_grad():
+        content, _ = U.render_meshes(renderer, mesh0, cams)
+    plan = vgg.plan(B, S)
+
+    def grads(cam_slice, denom):
+        mesh = U.build_mesh(out["verts_uvs"], out["faces_uvs"], tex, out["verts"], out["faces"])
+        cur, _ = U.render_meshes(renderer, mesh, cams[cam_slice])
+        n = cur.shape[0]
+        loss = L.compute_perceptual_loss(cur, content[cam_slice], sty.expand(n, -1, -1, -1), vgg.__class__ and vgg,
+                                         batch_denom=denom)
+        tex.grad = None
+        loss.backward()
+        return loss.detach().clone(), tex.grad.clone(), cur.detach()
+    l8, g8, cur8 = grads(slice(0, 8), 8)
+    l8b, g8b, _ = grads(slice(0, 8), 8)
+    assert l8.item() == l8b.item()                                   # ordered reductions: bitwise reproducible loss
+    assert float((g8 - g8b).norm() / g8.norm()) <= 1e-5               # texture scatter uses float atomics (order varies)
+    # two plans of batch 4 with batch_denom 8 (what two ranks would compute)
+    la, ga, _ = grads(slice(0, 4), 8)
+    lb, gb, _ = grads(slice(4, 8), 8)
+    assert abs((la + lb).item() - l8.item()) <= 2e-5 * abs(l8.item())
+    assert float((ga + gb - g8).norm() / g8.norm()) <= 2e-4
+    # adjointness at full size: <g, render(tex + d) - render(tex)> == <scatter(g), d>
+    from st3d import ops
+    with torch.no_grad():
+        d = torch.randn_like(tex) * 0.01
+        mesh_d = U.build_mesh(out["verts_uvs"], out["faces_uvs"], tex + d, out["verts"], out["faces"])
+        cur_d, _ = U.render_meshes(renderer, mesh_d, cams)
+        gimg = torch.randn_like(cur8)
+        lhs = float((gimg.double() * (cur_d.double() - cur8.double())).sum())
+    mesh = U.build_mesh(out["verts_uvs"], out["faces_uvs"], tex, out["verts"], out["faces"])
+    cur, _ = U.render_meshes(renderer, mesh, cams)
+    tex.grad = None
+    cur.backward(gimg)
+    rhs = float((tex.grad.double() * d.double()).sum())
+    assert abs(lhs - rhs) <= 1e-3 * max(abs(lhs), abs(rhs))
+    # optimisation makes progress
+    losses = []
+    for _ in range(5):
+        out["optimizer"].zero_grad()
+        mesh = U.build_mesh(out["verts_uvs"], out["faces_uvs"], tex, out["verts"], out["faces"])
+        cur, _ = U.render_meshes(renderer, mesh, cams)
+        loss = L.compute_perceptual_loss(cur, content, sty.expand(B, -1, -1, -1), vgg)
+        loss.backward()
+        out["optimizer"].step()
+        losses.append(loss.item())
+    assert losses[-1] < losses[0] and all(np.isfinite(losses))

@@ -1,0 +1,154 @@
+"""Host-side logic that needs no GPU: OBJ/MTL reader + writer, cameras, containers, view
+sharding, CLI flag surface, error behaviour of the drop-in modules."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import render_ref as rr
+
+
+def test_obj_reader_tokens_fan_triangulation_and_negative_indices(tmp_path):
+    from st3d import io as stio
+    from PIL import Image
+    Image.fromarray(np.full((4, 4, 3), 128, np.uint8)).save(tmp_path / "t.png")
+    (tmp_path / "m.mtl").write_text("newmtl mat\nmap_Kd t.png\nKd 1 1 1\n")
+    (tmp_path / "m.obj").write_text(
+        "mtllib m.mtl\nusemtl mat\n"
+        "v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 0 0 1\n"
+        "vt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\n"
+        "vn 0 0 1\n"
+        "f 1/1/1 2/2/1 3/3/1 4/4/1\n"        # quad -> fan (0,1,2),(0,2,3)
+        "f -1/1 -5/2 -4/3\n")                  # negative = relative to the end
+    verts, faces, aux = stio.load_obj(str(tmp_path / "m.obj"))
+    assert verts.shape == (5, 3)
+    assert faces.verts_idx.tolist() == [[0, 1, 2], [0, 2, 3], [4, 0, 1]]
+    assert faces.textures_idx.tolist() == [[0, 1, 2], [0, 2, 3], [0, 1, 2]]
+    assert aux.verts_uvs.shape == (4, 2)
+    tex = list(aux.texture_images.values())[0]
+    assert tex.shape == (4, 4, 3) and abs(float(tex[0, 0, 0]) - 128 / 255) < 1e-6
+    # round trip through the writer
+    stio.save_obj(str(tmp_path / "out.obj"), verts, faces.verts_idx, aux.verts_uvs, faces.textures_idx, tex)
+    v2, f2, a2 = stio.load_obj(str(tmp_path / "out.obj"))
+    assert torch.allclose(v2, verts) and f2.verts_idx.tolist() == faces.verts_idx.tolist()
+    assert os.path.exists(tmp_path / "out.mtl") and os.path.exists(tmp_path / "out.png")
+
+
+def test_obj_without_uvs_reports_none(tmp_path):
+    """teapot-style faces `v//vn`: no UVs, and synthesize_uvs gives a usable set."""
+    from st3d import io as stio
+    (tmp_path / "t.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nf 1//1 2//1 3//1\n")
+    verts, faces, aux = stio.load_obj(str(tmp_path / "t.obj"))
+    assert faces.textures_idx is None and aux.verts_uvs is None and aux.texture_images is None
+    uv = stio.synthesize_uvs(verts)
+    assert uv.shape == (3, 2) and float(uv.min()) >= 0 and float(uv.max()) <= 1
+
+
+def test_cameras_match_the_oracle_restatement():
+    from st3d import render as R
+    elev = torch.tensor([12.0, -40.0, 89.0])
+    azim = torch.tensor([30.0, -150.0, 5.0])
+    Rt, Tt = R.look_at_view_transform(dist=2.10, elev=elev, azim=azim, at=((0, 0.10, 0.25),))
+    Rn, Tn = rr.look_at_view_transform(2.10, elev.numpy(), azim.numpy(), at=(0, 0.10, 0.25))
+    np.testing.assert_allclose(Rt.numpy(), Rn, atol=2e-6)
+    np.testing.assert_allclose(Tt.numpy(), Tn, atol=2e-6)
+    m = R.RotateAxisAngle(37.0, axis="X").get_matrix()[..., :3, :3].squeeze(0)
+    np.testing.assert_allclose(m.numpy(), rr.rotate_axis_angle(37.0, "X"), atol=1e-6)
+    cams = R.FoVPerspectiveCameras(R=Rt, T=Tt)
+    assert len(cams) == 3 and cams[1].R.shape == (1, 3, 3)
+    Rj, Tj = R.join_cameras([cams[0], cams[2]])
+    assert torch.equal(Rj, Rt[[0, 2]]) and torch.equal(Tj, Tt[[0, 2]])
+
+
+def test_fixed_cameras_and_random_cameras_shapes():
+    import utils as U
+    U.device = torch.device("cpu")
+    c = U.build_fixed_cameras(12, shuffle=False)
+    Rn, Tn = rr.fixed_cameras(12)
+    np.testing.assert_allclose(c.R.numpy(), Rn, atol=1e-6)
+    np.testing.assert_allclose(c.T.numpy(), Tn, atol=1e-6)
+    g = torch.Generator().manual_seed(0)
+    c2 = U.build_random_cameras(5, generator=g)
+    g = torch.Generator().manual_seed(0)
+    elev, azim = rr.random_camera_angles(5, lambda k: torch.rand(k, generator=g).numpy())
+    Rn, Tn = rr.look_at_view_transform(2.10, elev, azim, at=(0, 0.10, 0.25))
+    np.testing.assert_allclose(c2.R.numpy(), Rn, atol=5e-6)
+    np.testing.assert_allclose(c2.T.numpy(), Tn, atol=5e-6)
+
+
+def test_containers_and_setup_optimizations_keys():
+    import utils as U
+    verts = torch.rand(5, 3)
+    faces = torch.tensor([[0, 1, 2], [2, 3, 4]])
+    mesh = U.build_mesh(torch.rand(1, 6, 2), torch.tensor([[[0, 1, 2], [3, 4, 5]]]), torch.rand(1, 8, 8, 3), verts, faces)
+    assert mesh.verts_padded().shape == (1, 5, 3) and mesh.faces_packed().shape == (2, 3)
+    assert mesh.textures.maps_padded().shape == (1, 8, 8, 3)
+    with pytest.raises(ValueError):
+        U.build_mesh(torch.rand(1, 6, 2), torch.tensor([[[0, 1, 9]]]), torch.rand(1, 8, 8, 3), verts, faces).textures.faces_uvs_i32()
+    for target, leaves in (("texture", {"texture_map"}), ("mesh", {"verts"}), ("both", {"texture_map", "verts"})):
+        out = U.setup_optimizations(target, mesh, 0.01)
+        assert set(out) == {"optimizable_mesh", "optimizer", "texture_map", "verts", "faces", "verts_uvs", "faces_uvs"}
+        assert {k for k in ("texture_map", "verts") if out[k].requires_grad} == leaves
+        assert out["texture_map"].data_ptr() != mesh.textures.maps_padded().data_ptr()      # a clone is optimised
+    fin = U.finalize_mesh(U.build_mesh(torch.rand(1, 6, 2), torch.tensor([[[0, 1, 2]]]), torch.rand(1, 4, 4, 3) * 3 - 1, verts, faces))
+    t = fin.textures.maps_padded()
+    assert float(t.min()) >= 0 and float(t.max()) <= 1 and not t.requires_grad
+
+
+def test_apply_background_white_is_identity_and_tensor_to_image():
+    import utils as U
+    t = torch.rand(2, 3, 4, 4)
+    assert U.apply_background(t, torch.ones(2, 1, 4, 4), background_type="white") is t
+    img = U.tensor_to_image(torch.tensor([[[1.5]], [[0.5]], [[-1.0]]]))
+    assert img.getpixel((0, 0)) == (255, 127, 0)
+
+
+def test_shard_views_partitions_every_batch():
+    from st3d.optim import shard_views
+    for n in (1, 7, 8, 64):
+        for world in (1, 2, 3, 8):
+            spans = [shard_views(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_cli_flags_and_defaults_match_the_reference():
+    import first_approach as FA
+    import second_approach as SA
+    a = SA.build_parser().parse_args([])
+    assert (a.n_views, a.epochs, a.size, a.batch_size, a.lr, a.style_weight, a.content_weight) == (6, 3000, 768, 4, 0.01, 1e6, 1.0)
+    assert (a.content_background, a.current_background, a.optimization_target, a.main_loss_weight) == ("white", "white", "texture", 3.0)
+    assert a.output_path == "/content/output_second" and a.resize_texture is True and a.randomize_views is True
+    b = FA.build_parser().parse_args([])
+    assert (b.n_mse_steps, b.n_style_transfer_steps, b.style_transfer_init, b.mse_lr, b.style_transfer_lr) == (100, 3000, "content", 0.01, 0.01)
+    assert b.output_path == "/content/output_first"
+    # type=bool gotcha preserved: any non-empty string is True
+    assert SA.build_parser().parse_args(["--resize_texture", "False"]).resize_texture is True
+
+
+def test_unknown_opt_type_raises_unbound_local_error():
+    """losses.py:98,126 of the reference fall through to `return loss` with loss unbound."""
+    import losses as L
+    with pytest.raises(UnboundLocalError):
+        L.compute_first_approach_loss(None, None, None, None, None, None, {}, "nonsense")
+    with pytest.raises(UnboundLocalError):
+        L.compute_second_approach_loss(None, None, None, None, 1.0, 1.0, None, None, None, {}, "nonsense")
+
+
+def test_api_only_losses_match_the_oracle(golden_dir):
+    import losses as L
+    from oracle import perceptual_ref as P
+    d = np.load(os.path.join(golden_dir, "g3_perceptual.npz"))
+    cur, masks = torch.from_numpy(d["cur"]), torch.from_numpy(d["masks"])
+    assert abs(float(L.compute_tv_loss(cur, masks)) - float(d["tv_loss"])) <= 1e-6
+
+    class M:
+        class textures:
+            @staticmethod
+            def maps_padded():
+                return (cur * 3 - 1).permute(0, 2, 3, 1)
+    assert abs(float(L.rgb_range_loss(M)) - float(d["rgb_range"])) <= 1e-2
+    assert abs(float(P.tv_loss_ref(cur, masks)) - float(L.compute_tv_loss(cur, masks))) <= 1e-7
