@@ -29,6 +29,7 @@ SOURCES = {
     "conv.hip": [],
     "gram.hip": [],
     "loss.hip": ["-ffp-contract=off"],
+    "mesh.hip": [],
     "plan.hip": [],
 }
 

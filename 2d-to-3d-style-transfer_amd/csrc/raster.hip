@@ -212,3 +212,104 @@ extern "C" int st3d_raster_fwd(const float *verts_ndc, const int32_t *faces, int
     ST3D_LAUNCH_CHECK();
     return ST3D_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// Vertex path: backward of the perspective-correct barycentrics w.r.t. the
+// projected vertices and of the projection w.r.t. the world vertices.  One thread per pixel,
+// 9 float atomics per covered pixel into (B,V,3); the projection backward gathers over views
+// per vertex (no atomics).  Same derivation as oracle/raster_ref.c:ref_raster_bwd.
+namespace {
+
+__global__ __launch_bounds__(256) void raster_bwd_kernel(const float *__restrict__ gbary, const int32_t *__restrict__ p2f,
+                                                         const float *__restrict__ ndc, const int32_t *__restrict__ faces,
+                                                         int B, int V, int S, float *__restrict__ gndc) {
+    const size_t HW = (size_t)S * S;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * HW) return;
+    const int f = p2f[i];
+    if (f < 0) return;
+    const size_t b = i / HW, p = i - b * HW;
+    const int yi = (int)(p / S), xi = (int)(p - (size_t)yi * S);
+    const float px = pix_to_ndc(S - 1 - xi, S), py = pix_to_ndc(S - 1 - yi, S);
+    const float *vb = ndc + b * (size_t)V * 3;
+    const int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
+    const float x0 = vb[3 * i0], y0 = vb[3 * i0 + 1], z0 = vb[3 * i0 + 2];
+    const float x1 = vb[3 * i1], y1 = vb[3 * i1 + 1], z1 = vb[3 * i1 + 2];
+    const float x2 = vb[3 * i2], y2 = vb[3 * i2 + 1], z2 = vb[3 * i2 + 2];
+    const float A = edge_fn(x2, y2, x0, y0, x1, y1) + kEps;
+    const float w0 = edge_fn(px, py, x1, y1, x2, y2) / A;
+    const float w1 = edge_fn(px, py, x2, y2, x0, y0) / A;
+    const float w2 = edge_fn(px, py, x0, y0, x1, y1) / A;
+    const float t0 = w0 * z1 * z2, t1 = z0 * w1 * z2, t2 = z0 * z1 * w2;
+    const float den = t0 + t1 + t2;
+    if (!(den > kEps)) return;
+    const float b0 = t0 / den, b1 = t1 / den, b2 = t2 / den;
+    const float g0 = gbary[3 * i], g1 = gbary[3 * i + 1], g2 = gbary[3 * i + 2];
+    const float gs = g0 * b0 + g1 * b1 + g2 * b2;
+    const float dt0 = (g0 - gs) / den, dt1 = (g1 - gs) / den, dt2 = (g2 - gs) / den;
+    const float dw0 = dt0 * z1 * z2, dw1 = dt1 * z0 * z2, dw2 = dt2 * z0 * z1;
+    const float dz0 = dt1 * w1 * z2 + dt2 * z1 * w2;
+    const float dz1 = dt0 * w0 * z2 + dt2 * z0 * w2;
+    const float dz2 = dt0 * w0 * z1 + dt1 * z0 * w1;
+    const float de0 = dw0 / A, de1 = dw1 / A, de2 = dw2 / A;
+    const float dA = -(dw0 * w0 + dw1 * w1 + dw2 * w2) / A;
+    float gx0 = de1 * -(py - y2) + de2 * (py - y1) + dA * (y2 - y1);
+    float gy0 = de1 * (px - x2) + de2 * (x1 - px) + dA * (x1 - x2);
+    float gx1 = de0 * (py - y2) + de2 * -(py - y0) + dA * -(y2 - y0);
+    float gy1 = de0 * (x2 - px) + de2 * (px - x0) + dA * (x2 - x0);
+    float gx2 = de0 * -(py - y1) + de1 * (py - y0) + dA * (y1 - y0);
+    float gy2 = de0 * (px - x1) + de1 * (x0 - px) + dA * -(x1 - x0);
+    float *gb = gndc + b * (size_t)V * 3;
+    atomicAdd(gb + 3 * i0, gx0); atomicAdd(gb + 3 * i0 + 1, gy0); atomicAdd(gb + 3 * i0 + 2, dz0);
+    atomicAdd(gb + 3 * i1, gx1); atomicAdd(gb + 3 * i1 + 1, gy1); atomicAdd(gb + 3 * i1 + 2, dz1);
+    atomicAdd(gb + 3 * i2, gx2); atomicAdd(gb + 3 * i2 + 1, gy2); atomicAdd(gb + 3 * i2 + 2, dz2);
+}
+
+__global__ void project_verts_bwd_kernel(const float *__restrict__ verts, int V, const float *__restrict__ R,
+                                         const float *__restrict__ T, int B, float s, const float *__restrict__ gndc,
+                                         int accumulate, float *__restrict__ gverts) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    const float x = verts[3 * v], y = verts[3 * v + 1], z = verts[3 * v + 2];
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float *r = R + 9 * b, *t = T + 3 * b;
+        const float xv = x * r[0] + y * r[3] + z * r[6] + t[0];
+        const float yv = x * r[1] + y * r[4] + z * r[7] + t[1];
+        const float zv = x * r[2] + y * r[5] + z * r[8] + t[2];
+        const float *g = gndc + ((size_t)b * V + v) * 3;
+        const float dxv = s * g[0] / zv, dyv = s * g[1] / zv;
+        const float dzv = g[2] - s * (g[0] * xv + g[1] * yv) / (zv * zv);
+        ax += dxv * r[0] + dyv * r[1] + dzv * r[2];
+        ay += dxv * r[3] + dyv * r[4] + dzv * r[5];
+        az += dxv * r[6] + dyv * r[7] + dzv * r[8];
+    }
+    if (accumulate) { ax += gverts[3 * v]; ay += gverts[3 * v + 1]; az += gverts[3 * v + 2]; }
+    gverts[3 * v] = ax; gverts[3 * v + 1] = ay; gverts[3 * v + 2] = az;
+}
+
+}  // namespace
+
+extern "C" int st3d_raster_bwd(const float *grad_bary, const int32_t *pix_to_face, const float *verts_ndc,
+                               const int32_t *faces, int B, int V, int F, int S, float *grad_verts_ndc,
+                               st3d_stream_t stream) {
+    ST3D_CHECK_ARG(grad_bary && pix_to_face && verts_ndc && faces && grad_verts_ndc);
+    ST3D_CHECK_ARG(B > 0 && V > 0 && F > 0 && S > 0);
+    hipStream_t s = st3d::as_stream(stream);
+    ST3D_HIP(hipMemsetAsync(grad_verts_ndc, 0, (size_t)B * V * 3 * sizeof(float), s));
+    const size_t n = (size_t)B * S * S;
+    raster_bwd_kernel<<<st3d::cdiv((long)n, 256), 256, 0, s>>>(grad_bary, pix_to_face, verts_ndc, faces, B, V, S, grad_verts_ndc);
+    ST3D_LAUNCH_CHECK();
+    return ST3D_OK;
+}
+
+extern "C" int st3d_project_verts_bwd(const float *verts, int V, const float *R, const float *T, int B,
+                                      float inv_tan_half_fov, const float *grad_verts_ndc, int accumulate, float *grad_verts,
+                                      st3d_stream_t stream) {
+    ST3D_CHECK_ARG(verts && R && T && grad_verts_ndc && grad_verts);
+    ST3D_CHECK_ARG(V > 0 && B > 0);
+    project_verts_bwd_kernel<<<st3d::cdiv(V, 256), 256, 0, st3d::as_stream(stream)>>>(verts, V, R, T, B, inv_tan_half_fov,
+                                                                                      grad_verts_ndc, accumulate, grad_verts);
+    ST3D_LAUNCH_CHECK();
+    return ST3D_OK;
+}

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(const float *__restrict_
                                                         const float *__restrict__ dists, const float *__restrict__ uvs,
                                                         const int32_t *__restrict__ fuv, const float *__restrict__ tex,
                                                         int B, int S, int T, float *__restrict__ gtex,
-                                                        float *__restrict__ guv) {
+                                                        float *__restrict__ guv, float *__restrict__ gbary) {
     const size_t HW = (size_t)S * S;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)B * HW) return;
@@ -104,8 +104,10 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(const float *__restrict_
     const int f = p2f[i];
     if (f < 0) {
         if (guv) { guv[2 * i] = 0.f; guv[2 * i + 1] = 0.f; }
+        if (gbary) { gbary[3 * i] = 0.f; gbary[3 * i + 1] = 0.f; gbary[3 * i + 2] = 0.f; }
         return;
     }
+    const bool want_uv = guv || gbary;
     const float b0 = bary[3 * i], b1 = bary[3 * i + 1], b2 = bary[3 * i + 2];
     const int u0 = fuv[3 * f], u1 = fuv[3 * f + 1], u2 = fuv[3 * f + 2];
     const float u = b0 * uvs[2 * u0] + b1 * uvs[2 * u1] + b2 * uvs[2 * u2];
@@ -122,16 +124,20 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(const float *__restrict_
     for (int c = 0; c < 3; ++c) {
         const float gc = g[c * HW] * k;
         float t00 = 0.f, t01 = 0.f, t10 = 0.f, t11 = 0.f;
-        if (q.vy0 && q.vx0) { atomicAdd(gtex + o00 + c, gc * w00); if (guv) t00 = tex[o00 + c]; }
-        if (q.vy0 && q.vx1) { atomicAdd(gtex + o01 + c, gc * w01); if (guv) t01 = tex[o01 + c]; }
-        if (q.vy1 && q.vx0) { atomicAdd(gtex + o10 + c, gc * w10); if (guv) t10 = tex[o10 + c]; }
-        if (q.vy1 && q.vx1) { atomicAdd(gtex + o11 + c, gc * w11); if (guv) t11 = tex[o11 + c]; }
+        if (q.vy0 && q.vx0) { if (gtex) atomicAdd(gtex + o00 + c, gc * w00); if (want_uv) t00 = tex[o00 + c]; }
+        if (q.vy0 && q.vx1) { if (gtex) atomicAdd(gtex + o01 + c, gc * w01); if (want_uv) t01 = tex[o01 + c]; }
+        if (q.vy1 && q.vx0) { if (gtex) atomicAdd(gtex + o10 + c, gc * w10); if (want_uv) t10 = tex[o10 + c]; }
+        if (q.vy1 && q.vx1) { if (gtex) atomicAdd(gtex + o11 + c, gc * w11); if (want_uv) t11 = tex[o11 + c]; }
         gix += gc * ((t01 - t00) * q.wy0 + (t11 - t10) * q.wy1);
         giy += gc * ((t10 - t00) * q.wx0 + (t11 - t01) * q.wx1);
     }
-    if (guv) {
-        guv[2 * i] = q.cx ? 0.f : gix * (float)(T - 1);
-        guv[2 * i + 1] = q.cy ? 0.f : giy * (float)(T - 1);
+    const float gu = q.cx ? 0.f : gix * (float)(T - 1);
+    const float gv = q.cy ? 0.f : giy * (float)(T - 1);
+    if (guv) { guv[2 * i] = gu; guv[2 * i + 1] = gv; }
+    if (gbary) {      // uv = sum_i b_i * uv_i
+        gbary[3 * i] = gu * uvs[2 * u0] + gv * uvs[2 * u0 + 1];
+        gbary[3 * i + 1] = gu * uvs[2 * u1] + gv * uvs[2 * u1 + 1];
+        gbary[3 * i + 2] = gu * uvs[2 * u2] + gv * uvs[2 * u2 + 1];
     }
 }
 
@@ -165,12 +171,13 @@ extern "C" int st3d_shade_fwd(const int32_t *pix_to_face, const float *bary, con
 extern "C" int st3d_shade_bwd(const float *grad_rgb, const int32_t *pix_to_face, const float *bary, const float *zbuf,
                               const float *dists, const float *verts_uvs, const int32_t *faces_uvs, const float *texture,
                               int B, int S, int T, int F, int VT, float *grad_texture, float *grad_uv,
-                              st3d_stream_t stream) {
-    ST3D_CHECK_ARG(grad_rgb && pix_to_face && bary && zbuf && dists && verts_uvs && faces_uvs && texture && grad_texture);
+                              float *grad_bary, st3d_stream_t stream) {
+    ST3D_CHECK_ARG(grad_rgb && pix_to_face && bary && zbuf && dists && verts_uvs && faces_uvs && texture);
+    ST3D_CHECK_ARG(grad_texture || grad_uv || grad_bary);
     ST3D_CHECK_ARG(B > 0 && S > 0 && T > 1 && F > 0 && VT > 0);
     const size_t n = (size_t)B * S * S;
     shade_bwd_kernel<<<st3d::cdiv((long)n, 256), 256, 0, st3d::as_stream(stream)>>>(
-        grad_rgb, pix_to_face, bary, zbuf, dists, verts_uvs, faces_uvs, texture, B, S, T, grad_texture, grad_uv);
+        grad_rgb, pix_to_face, bary, zbuf, dists, verts_uvs, faces_uvs, texture, B, S, T, grad_texture, grad_uv, grad_bary);
     ST3D_LAUNCH_CHECK();
     return ST3D_OK;
 }

@@ -95,10 +95,7 @@ def _masked_mse(rendered, masks, target_rendered):
 def _mesh_terms(verts, target_verts, mesh, weights):
     """The four view-independent regularisers both approaches add for 'mesh'/'both'
     (reference losses.py:84-87,93-96,112-115,121-124), same weights-dict keys."""
-    return (weights['mesh_verts_weight'] * _mesh_losses.verts_mse(verts, target_verts)
-            + weights['mesh_edge_loss_weight'] * mesh_edge_loss(mesh)
-            + weights['mesh_laplacian_smoothing_weight'] * mesh_laplacian_smoothing(mesh)
-            + weights['mesh_normal_consistency_weight'] * mesh_normal_consistency(mesh))
+    return _mesh_losses.mesh_terms(verts, target_verts, mesh, weights)      # one fused forward+gradient call
 
 
 def compute_first_approach_loss(rendered, masks, target_rendered, verts, target_verts, mesh, weights, opt_type):

@@ -1,24 +1,164 @@
-"""View-independent mesh regularisers of the 'mesh' / 'both' optimisation targets
-(reference losses.py:84-87 via pytorch3d.loss).  Not built yet (SURVEY.md 8,
-kernels K14/K15 -- the texture target of configs 1-4 does not reach them): they fail loudly."""
+"""View-independent mesh regularisers of the 'mesh' / 'both' optimisation targets on libst3d
+(reference losses.py:84-87,93-96,112-115,121-124 via ``pytorch3d.loss``).
+
+The three PyTorch3D names are kept (``mesh_edge_loss(mesh)``, ``mesh_laplacian_smoothing(mesh)``,
+``mesh_normal_consistency(mesh)``) plus ``verts_mse`` for ``F.mse_loss(verts, target_verts)``.
+Each returns a scalar tensor with an autograd edge to ``mesh.verts_packed()``; all four terms of
+one mesh are computed by ONE st3d_mesh_reg call (forward + gradient) which is cached on the
+vertex tensor's identity/version, so the reference's four separate calls cost one launch group.
+Topology (unique edges, CSR adjacency, face pairs) is static: built once per faces tensor on the
+host, cached.
+"""
+import torch
+
+from . import ops
+
+_TOPO_CACHE = {}
+_REG_CACHE = {}
 
 
-def _todo(name):
-    raise NotImplementedError(f"{name}: the vertex-optimisation path (optimization_target 'mesh'/'both') is not built "
-                              "yet; optimization_target 'texture' is")
+def build_topology(faces, num_verts):
+    """faces (F,3) int64 -> dict of int32 device tensors: edges (E,2) unique undirected in
+    ascending (min*V+max) order, CSR adjacency nbr_off (V+1)/nbr_idx, pairs (P,4) = (v0,v1,a,b)
+    for every two faces sharing edge (v0<v1) with opposite vertices a,b (all pairs for
+    non-manifold edges, none for boundary edges), PyTorch3D's enumeration order."""
+    dev = faces.device
+    f = faces.detach().long().cpu()
+    F = f.shape[0]
+    V = int(num_verts)
+    he = torch.cat([f[:, [1, 2]], f[:, [2, 0]], f[:, [0, 1]]], dim=0)               # (3F,2)
+    he = torch.sort(he, dim=1).values
+    key = he[:, 0] * V + he[:, 1]
+    ukey, inv = torch.unique(key, sorted=True, return_inverse=True)
+    edges = torch.stack([ukey // V, ukey % V], dim=1)
+    E = edges.shape[0]
+    # CSR adjacency (both directions)
+    src = torch.cat([edges[:, 0], edges[:, 1]])
+    dst = torch.cat([edges[:, 1], edges[:, 0]])
+    order = torch.sort(src * V + dst).indices
+    src, dst = src[order], dst[order]
+    deg = torch.bincount(src, minlength=V)
+    off = torch.zeros(V + 1, dtype=torch.int64)
+    off[1:] = torch.cumsum(deg, 0)
+    # face pairs per shared edge
+    f2e = inv.reshape(3, F).t()                                                      # (F,3): edge of half-edges v1v2, v2v0, v0v1
+    edge_idx = f2e.reshape(F * 3)
+    opp = f.view(F, 1, 3).expand(F, 3, 3).reshape(F * 3, 3).sum(1)                   # sum of the face's 3 vertices
+    edge_idx, o2 = torch.sort(edge_idx, stable=True)
+    opp = opp[o2] - edges[edge_idx, 0] - edges[edge_idx, 1]                          # the vertex opposite the edge
+    cnt = torch.bincount(edge_idx, minlength=E)
+    start = torch.cumsum(cnt, 0) - cnt
+    two = (cnt == 2).nonzero().flatten()
+    pairs = [torch.stack([edges[two, 0], edges[two, 1], opp[start[two]], opp[start[two] + 1]], dim=1)]
+    order_keys = [two * 0 + two]                                                     # sort key: edge index
+    for e in (cnt > 2).nonzero().flatten().tolist():                                 # non-manifold edges: all pairs i<j
+        s, c = int(start[e]), int(cnt[e])
+        rows = [(int(edges[e, 0]), int(edges[e, 1]), int(opp[s + i]), int(opp[s + j])) for i in range(c) for j in range(i + 1, c)]
+        pairs.append(torch.tensor(rows, dtype=torch.int64))
+        order_keys.append(torch.full((len(rows),), e, dtype=torch.int64))
+    pairs = torch.cat(pairs, 0) if pairs else torch.zeros((0, 4), dtype=torch.int64)
+    keys = torch.cat(order_keys, 0)
+    pairs = pairs[torch.sort(keys, stable=True).indices]
+    i32 = lambda t: t.to(torch.int32).contiguous().to(dev)
+    return {"edges": i32(edges), "nbr_off": i32(off), "nbr_idx": i32(dst), "pairs": i32(pairs.reshape(-1, 4))}
+
+
+def _topology(mesh):
+    faces = mesh.faces_packed()
+    V = mesh.verts_packed().shape[0]
+    key = (faces.data_ptr(), tuple(faces.shape), faces._version, V, str(faces.device))
+    hit = _TOPO_CACHE.get(key)
+    if hit is None:
+        if len(_TOPO_CACHE) > 16:
+            _TOPO_CACHE.clear()
+        hit = (build_topology(faces, V), faces)
+        _TOPO_CACHE[key] = hit
+    return hit[0]
+
+
+class _TermFn(torch.autograd.Function):
+    """One regulariser term: value = loss_out[k], gradient = unit-weight gradient of that term."""
+
+    @staticmethod
+    def forward(ctx, verts, value, grad):
+        ctx.grad = grad
+        return value.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.grad * g, None, None
+
+
+def _term(verts, target, topo, k):
+    """k: 0 mse, 1 edge, 2 laplacian, 3 normal.  Terms are evaluated with unit weight each (four
+    calls of st3d_mesh_reg would be wasteful: results are cached per (verts version, k))."""
+    if not verts.is_cuda:
+        raise RuntimeError("st3d runs on the GPU (libst3d); got CPU tensors -- there is no CPU fallback")
+    key = (verts.data_ptr(), verts._version, k, None if target is None else target.data_ptr())
+    hit = _REG_CACHE.get(key)
+    if hit is None:
+        if len(_REG_CACHE) > 8:
+            _REG_CACHE.clear()
+        w = [0.0, 0.0, 0.0, 0.0]
+        w[k] = 1.0
+        tgt = target if target is not None else verts
+        out, grad = ops.mesh_reg(verts.detach(), tgt.detach(), topo, w, want_grad=True)
+        hit = (out[1 + k], grad)
+        _REG_CACHE[key] = hit
+    return _TermFn.apply(verts, hit[0], hit[1])
+
+
+class _VertsMseFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, verts, target):
+        n = verts.numel()
+        out, D = ops.sqdiff_sum(verts.detach().to(torch.float32).contiguous(), target.detach().to(torch.float32).contiguous(),
+                                scale=1.0 / n, want_diff=True)
+        ctx.D, ctx.n, ctx.shape = D, n, verts.shape
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (ctx.D * (2.0 / ctx.n) * g).reshape(ctx.shape), None
 
 
 def verts_mse(verts, target_verts):
-    _todo("verts_mse")
+    """F.mse_loss(verts, target_verts) (reference losses.py:84)."""
+    if not verts.is_cuda:
+        raise RuntimeError("st3d runs on the GPU (libst3d); got CPU tensors -- there is no CPU fallback")
+    return _VertsMseFn.apply(verts, target_verts)
 
 
-def mesh_edge_loss(mesh):
-    _todo("mesh_edge_loss")
+def mesh_edge_loss(mesh, target_length=0.0):
+    if target_length != 0.0:
+        raise NotImplementedError("the reference calls mesh_edge_loss(mesh) with the default target_length=0")
+    return _term(mesh.verts_packed(), None, _topology(mesh), 1)
 
 
 def mesh_laplacian_smoothing(mesh, method="uniform"):
-    _todo("mesh_laplacian_smoothing")
+    if method != "uniform":
+        raise NotImplementedError("the reference uses the default method='uniform'")
+    return _term(mesh.verts_packed(), None, _topology(mesh), 2)
 
 
 def mesh_normal_consistency(mesh):
-    _todo("mesh_normal_consistency")
+    return _term(mesh.verts_packed(), None, _topology(mesh), 3)
+
+
+def mesh_terms(verts, target_verts, mesh, weights):
+    """All four weighted terms in ONE st3d_mesh_reg call (what losses._mesh_terms uses):
+    weights: dict with the reference's keys (first_approach.py:69-75)."""
+    if not verts.is_cuda:
+        raise RuntimeError("st3d runs on the GPU (libst3d); got CPU tensors -- there is no CPU fallback")
+    topo = _topology(mesh)
+    w = [weights['mesh_verts_weight'], weights['mesh_edge_loss_weight'], weights['mesh_laplacian_smoothing_weight'],
+         weights['mesh_normal_consistency_weight']]
+    # the terms are view-independent: when the view batch is sharded over ranks every rank computes them, so each
+    # contributes 1/world and the all-reduced (summed) gradient/loss counts them once
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        w = [x / dist.get_world_size() for x in w]
+    out, grad = ops.mesh_reg(verts.detach(), target_verts.detach(), topo, w, want_grad=verts.requires_grad)
+    if grad is None:
+        return out[0].clone()
+    return _TermFn.apply(verts, out[0], grad)

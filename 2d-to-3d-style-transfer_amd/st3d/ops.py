@@ -54,18 +54,66 @@ def shade_fwd(frag, verts_uvs, faces_uvs_i32, texture):
     return rgb, mask
 
 
-def shade_bwd(grad_rgb, frag, verts_uvs, faces_uvs_i32, texture, grad_texture=None, want_uv=False):
+def shade_bwd(grad_rgb, frag, verts_uvs, faces_uvs_i32, texture, grad_texture=None, want_uv=False, want_bary=False,
+              want_texture=True):
+    """-> grad_texture (T,T,3) [, grad_uv (B,S,S,2)] [, grad_bary (B,S,S,3)]"""
     p2f, zbuf, bary, dists = frag
     B, S, _ = p2f.shape
     T = texture.shape[0]
-    if grad_texture is None:
+    if grad_texture is None and want_texture:
         grad_texture = torch.zeros((T, T, 3), dtype=F32, device=p2f.device)
     guv = torch.empty((B, S, S, 2), dtype=F32, device=p2f.device) if want_uv else None
+    gbary = torch.empty((B, S, S, 3), dtype=F32, device=p2f.device) if want_bary else None
     grad_rgb = grad_rgb.contiguous()
     call("st3d_shade_bwd", dptr(grad_rgb, F32), dptr(p2f, I32), dptr(bary, F32), dptr(zbuf, F32), dptr(dists, F32),
          dptr(verts_uvs, F32), dptr(faces_uvs_i32, I32), dptr(texture, F32), B, S, T, faces_uvs_i32.shape[0],
-         verts_uvs.shape[0], dptr(grad_texture, F32), dptr(guv), stream_ptr())
-    return (grad_texture, guv) if want_uv else grad_texture
+         verts_uvs.shape[0], dptr(grad_texture, F32) if grad_texture is not None else None, dptr(guv), dptr(gbary),
+         stream_ptr())
+    out = (grad_texture,)
+    if want_uv:
+        out += (guv,)
+    if want_bary:
+        out += (gbary,)
+    return out if len(out) > 1 else out[0]
+
+
+def raster_bwd(grad_bary, p2f, verts_ndc, faces_i32):
+    """grad_bary (B,S,S,3) -> grad_verts_ndc (B,V,3)"""
+    B, V, _ = verts_ndc.shape
+    S = p2f.shape[1]
+    g = torch.empty((B, V, 3), dtype=F32, device=verts_ndc.device)
+    call("st3d_raster_bwd", dptr(grad_bary, F32), dptr(p2f, I32), dptr(verts_ndc, F32), dptr(faces_i32, I32), B, V,
+         faces_i32.shape[0], S, dptr(g), stream_ptr())
+    return g
+
+
+def project_verts_bwd(verts, R, T, grad_ndc, out=None):
+    verts, R, T = _f32c(verts), _f32c(R), _f32c(T)
+    acc = 1
+    if out is None:
+        out = torch.empty_like(verts)
+        acc = 0
+    call("st3d_project_verts_bwd", dptr(verts), verts.shape[0], dptr(R), dptr(T), R.shape[0], INV_TAN_HALF_FOV,
+         dptr(grad_ndc, F32), acc, dptr(out), stream_ptr())
+    return out
+
+
+def mesh_reg(verts, target, topo, weights, want_grad=True):
+    """topo: dict(edges (E,2) i32, nbr_off (V+1) i32, nbr_idx i32, pairs (P,4) i32).
+    -> (loss_out [weighted total, mse, edge, laplacian, normal], grad_verts (V,3) or None)"""
+    verts, target = _f32c(verts), _f32c(target)
+    V = verts.shape[0]
+    dev = verts.device
+    scratch = torch.empty((3 * V,), dtype=F32, device=dev)
+    parts = torch.empty((4 * _lib.load().st3d_reduce_partials(),), dtype=F32, device=dev)
+    out = torch.zeros((5,), dtype=F32, device=dev)
+    g = torch.zeros_like(verts) if want_grad else None
+    w = (ctypes.c_float * 4)(*[float(x) for x in weights])
+    P = topo["pairs"].shape[0]
+    call("st3d_mesh_reg", dptr(verts), dptr(target), V, dptr(topo["edges"], I32), topo["edges"].shape[0],
+         dptr(topo["nbr_off"], I32), dptr(topo["nbr_idx"], I32), dptr(topo["pairs"], I32) if P else None, P, w,
+         dptr(scratch), dptr(parts), dptr(out), dptr(g), stream_ptr())
+    return out, g
 
 
 def apply_background(img, mask, bg=None):

@@ -239,7 +239,8 @@ class SoftPhongShader:
 
 
 class _RenderFn(torch.autograd.Function):
-    """(verts, texture_map) -> (rgb (B,3,S,S), mask (B,1,S,S)); backward = texture scatter."""
+    """(verts, texture_map) -> (rgb (B,3,S,S), mask (B,1,S,S)); backward = texture scatter and,
+    when the vertices need a gradient, shade d/d(bary) -> raster backward -> projection backward."""
 
     @staticmethod
     def forward(ctx, verts, tex_map, faces_i32, verts_uvs, faces_uvs_i32, R, T, S):
@@ -253,19 +254,26 @@ class _RenderFn(torch.autograd.Function):
         rgb, mask = ops.shade_fwd(frag, uvs, faces_uvs_i32, tex)
         ctx.frag, ctx.uvs, ctx.fuv, ctx.tex = frag, uvs, faces_uvs_i32, tex
         ctx.tex_shape = tex_map.shape
-        ctx.verts_need_grad = verts.requires_grad
+        ctx.geom = (v, ndc, faces_i32, R, T)
+        ctx.verts_shape = verts.shape
         ctx.mark_non_differentiable(mask)
         return rgb, mask
 
     @staticmethod
     def backward(ctx, grad_rgb, _grad_mask):
-        if ctx.verts_need_grad:
-            raise NotImplementedError("vertex gradients (optimization_target 'mesh'/'both') are not built yet: "
-                                      "SURVEY.md 8 row K14; texture optimisation is")
-        gtex = None
-        if ctx.needs_input_grad[1]:
-            gtex = ops.shade_bwd(grad_rgb.to(torch.float32), ctx.frag, ctx.uvs, ctx.fuv, ctx.tex).reshape(ctx.tex_shape)
-        return None, gtex, None, None, None, None, None, None
+        need_v, need_t = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        gtex = gverts = None
+        if need_v or need_t:
+            res = ops.shade_bwd(grad_rgb.to(torch.float32), ctx.frag, ctx.uvs, ctx.fuv, ctx.tex, want_bary=need_v,
+                                want_texture=need_t)
+            gt, gbary = (res if need_v else (res, None))
+            if need_t:
+                gtex = gt.reshape(ctx.tex_shape)
+            if need_v:      # uv -> barycentrics -> projected vertices -> world vertices
+                v, ndc, faces_i32, R, T = ctx.geom
+                gndc = ops.raster_bwd(gbary, ctx.frag[0], ndc, faces_i32)
+                gverts = ops.project_verts_bwd(v, R, T, gndc).reshape(ctx.verts_shape)
+        return gverts, gtex, None, None, None, None, None, None
 
 
 def render_views(meshes, R, T, image_size):

@@ -72,11 +72,25 @@ int st3d_shade_fwd(const int32_t *pix_to_face, const float *bary, const float *z
 
 /* Texture-sampling backward (grid_sampler_2d_backward + blend backward):
  * grad_rgb (B,3,S,S) -> grad_texture (T,T,3), ACCUMULATED over the B views (caller zeroes).
- * grad_uv (B,S,S,2) optional (NULL for texture-only optimisation): d loss / d (u,v). */
+ * Optional outputs for the vertex path (NULL for texture-only optimisation): grad_uv (B,S,S,2)
+ * = d loss / d (u,v) and grad_bary (B,S,S,3) = d loss / d barycentrics (interpolate_face_attributes
+ * backward).  grad_texture may be NULL when only the vertices are optimised. */
 int st3d_shade_bwd(const float *grad_rgb, const int32_t *pix_to_face, const float *bary,
                    const float *zbuf, const float *dists, const float *verts_uvs,
                    const int32_t *faces_uvs, const float *texture, int B, int S, int T, int F,
-                   int VT, float *grad_texture, float *grad_uv, st3d_stream_t stream);
+                   int VT, float *grad_texture, float *grad_uv, float *grad_bary,
+                   st3d_stream_t stream);
+
+/* Rasteriser backward (PyTorch3D RasterizeMeshesBackward, grad_bary path; reached through
+ * loss.backward() at second_approach.py:188 when optimization_target is 'mesh'/'both'):
+ * grad_bary (B,S,S,3) -> grad_verts_ndc (B,V,3) (zeroed by the call, then atomically summed). */
+int st3d_raster_bwd(const float *grad_bary, const int32_t *pix_to_face, const float *verts_ndc,
+                    const int32_t *faces, int B, int V, int F, int S, float *grad_verts_ndc,
+                    st3d_stream_t stream);
+/* backward of st3d_project_verts: grad_verts (V,3) (+)= sum over the B views */
+int st3d_project_verts_bwd(const float *verts, int V, const float *R, const float *T, int B,
+                           float inv_tan_half_fov, const float *grad_verts_ndc, int accumulate,
+                           float *grad_verts, st3d_stream_t stream);
 
 /* apply_background, utils.py:19-30: out = img*mask + bg*(1-mask); bg (B,3,S,S) or, with
  * bg_batch == 1, one (3,S,S) image broadcast over the batch.  Optional grad path is the
@@ -136,6 +150,20 @@ int st3d_axpy_diff(const float *a, const float *b, size_t n, float coef, int acc
  * B*3*S*S; grad_r = 2*m*m*(r - t)/(B*3*S*S) (may be NULL). */
 int st3d_masked_mse(const float *rendered, const float *target, const float *mask, int B, int S,
                     float *grad_rendered, float *partials, float *loss_out, st3d_stream_t stream);
+
+/* ------------------------------------------------------------------ mesh regularisers:
+ * losses.py:84-87,93-96,112-115,121-124 -- F.mse_loss(verts, target), pytorch3d.loss
+ * mesh_edge_loss (target length 0), mesh_laplacian_smoothing('uniform'), mesh_normal_consistency
+ * for one mesh, forward + gradient in one call.  Topology is static and precomputed by the host:
+ * edges (E,2) unique undirected; CSR vertex adjacency nbr_off (V+1), nbr_idx; pairs (P,4) =
+ * (v0, v1, a, b) for every two faces sharing edge (v0,v1) with opposite vertices a, b.
+ * weights: host float[4] = {verts_mse, edge, laplacian, normal}.  scratch >= 3*V floats,
+ * partials >= 4*st3d_reduce_partials() floats.  loss_out: device float[5] = {weighted sum, mse,
+ * edge, laplacian, normal} (unweighted terms).  grad_verts (V,3) += weighted gradient. */
+int st3d_mesh_reg(const float *verts, const float *target_verts, int V, const int32_t *edges, int E,
+                  const int32_t *nbr_off, const int32_t *nbr_idx, const int32_t *pairs, int P,
+                  const float *weights, float *scratch, float *partials, float *loss_out,
+                  float *grad_verts, st3d_stream_t stream);
 
 /* ------------------------------------------------------------------ optimiser:
  * torch.optim.Adam defaults (utils.py:185-195, style_transfer.py:57) */

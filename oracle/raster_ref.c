@@ -293,3 +293,101 @@ void ref_adam_step(float *p, const float *g, float *m, float *v, size_t n, int s
         p[i] = p[i] - step_size * (m[i] / denom);
     }
 }
+
+/* ---------------------------------------------------------------- vertex path
+ * Backward of the rasteriser's perspective-correct barycentrics w.r.t. the projected vertices,
+ * and of the projection w.r.t. the world vertices -- what autograd does in the reference when
+ * optimization_target is 'mesh'/'both' (utils.py:187-195, second_approach.py:188) through
+ * PyTorch3D's RasterizeMeshesBackward (grad_bary path; the gradients through zbuf/dists are
+ * O(1e-10) via the K=1 blend, SURVEY.md A.4, and are not propagated).
+ * Accumulation in double.  PARITY UNPINNED (see the header); pinned by the fp64 autograd
+ * restatement in tests/test_oracle_vertex_path.py. */
+
+/* grad_uv (S,S,2) -> grad_bary (S,S,3): uv = sum_i b_i * uv_i */
+void ref_uv_to_bary_grad(const float *grad_uv, const int32_t *pix_to_face, const float *verts_uvs,
+                         const int32_t *faces_uvs, int S, float *grad_bary)
+{
+    const size_t HW = (size_t)S * S;
+    for (size_t p = 0; p < HW; ++p) {
+        const int f = pix_to_face[p];
+        for (int i = 0; i < 3; ++i) {
+            float g = 0.f;
+            if (f >= 0) {
+                const int ui = faces_uvs[3 * f + i];
+                g = grad_uv[2 * p] * verts_uvs[2 * ui] + grad_uv[2 * p + 1] * verts_uvs[2 * ui + 1];
+            }
+            grad_bary[3 * p + i] = g;
+        }
+    }
+}
+
+void ref_raster_bwd(const float *grad_bary, const int32_t *pix_to_face, const float *verts_ndc,
+                    const int32_t *faces, int S, double *grad_verts_ndc /* (V,3) accumulated */)
+{
+    for (int yi = 0; yi < S; ++yi) {
+        const float yf = pix_to_ndc(S - 1 - yi, S);
+        for (int xi = 0; xi < S; ++xi) {
+            const size_t p = (size_t)yi * S + xi;
+            const int f = pix_to_face[p];
+            if (f < 0) continue;
+            const float xf = pix_to_ndc(S - 1 - xi, S);
+            const int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
+            const double x0 = verts_ndc[3 * i0], y0 = verts_ndc[3 * i0 + 1], z0 = verts_ndc[3 * i0 + 2];
+            const double x1 = verts_ndc[3 * i1], y1 = verts_ndc[3 * i1 + 1], z1 = verts_ndc[3 * i1 + 2];
+            const double x2 = verts_ndc[3 * i2], y2 = verts_ndc[3 * i2 + 1], z2 = verts_ndc[3 * i2 + 2];
+            const double px = xf, py = yf;
+            const double A = ((x2 - x0) * (y1 - y0) - (y2 - y0) * (x1 - x0)) + (double)K_EPS;
+            const double e0 = (px - x1) * (y2 - y1) - (py - y1) * (x2 - x1);
+            const double e1 = (px - x2) * (y0 - y2) - (py - y2) * (x0 - x2);
+            const double e2 = (px - x0) * (y1 - y0) - (py - y0) * (x1 - x0);
+            const double w0 = e0 / A, w1 = e1 / A, w2 = e2 / A;
+            const double t0 = w0 * z1 * z2, t1 = z0 * w1 * z2, t2 = z0 * z1 * w2;
+            const double den = t0 + t1 + t2;
+            if (!(den > (double)K_EPS)) continue;                 /* clamped denominator: no gradient */
+            const double b0 = t0 / den, b1 = t1 / den, b2 = t2 / den;
+            const double g0 = grad_bary[3 * p], g1 = grad_bary[3 * p + 1], g2 = grad_bary[3 * p + 2];
+            const double gs = g0 * b0 + g1 * b1 + g2 * b2;
+            const double dt0 = (g0 - gs) / den, dt1 = (g1 - gs) / den, dt2 = (g2 - gs) / den;
+            const double dw0 = dt0 * z1 * z2, dw1 = dt1 * z0 * z2, dw2 = dt2 * z0 * z1;
+            const double dz0 = dt1 * w1 * z2 + dt2 * z1 * w2;
+            const double dz1 = dt0 * w0 * z2 + dt2 * z0 * w2;
+            const double dz2 = dt0 * w0 * z1 + dt1 * z0 * w1;
+            const double de0 = dw0 / A, de1 = dw1 / A, de2 = dw2 / A;
+            const double dA = -(dw0 * w0 + dw1 * w1 + dw2 * w2) / A;
+            /* E(p;a,b) = (px-ax)(by-ay) - (py-ay)(bx-ax):
+             *   dE/dax = py-by, dE/day = bx-px, dE/dbx = -(py-ay), dE/dby = px-ax,
+             *   dE/dpx = by-ay, dE/dpy = -(bx-ax) */
+            double gx0 = 0, gy0 = 0, gx1 = 0, gy1 = 0, gx2 = 0, gy2 = 0;
+            /* e0 = E(p; v1, v2) */
+            gx1 += de0 * (py - y2); gy1 += de0 * (x2 - px); gx2 += de0 * -(py - y1); gy2 += de0 * (px - x1);
+            /* e1 = E(p; v2, v0) */
+            gx2 += de1 * (py - y0); gy2 += de1 * (x0 - px); gx0 += de1 * -(py - y2); gy0 += de1 * (px - x2);
+            /* e2 = E(p; v0, v1) */
+            gx0 += de2 * (py - y1); gy0 += de2 * (x1 - px); gx1 += de2 * -(py - y0); gy1 += de2 * (px - x0);
+            /* A = E(v2; v0, v1) + eps */
+            gx0 += dA * (y2 - y1); gy0 += dA * (x1 - x2); gx1 += dA * -(y2 - y0); gy1 += dA * (x2 - x0);
+            gx2 += dA * (y1 - y0); gy2 += dA * -(x1 - x0);
+            grad_verts_ndc[3 * i0] += gx0; grad_verts_ndc[3 * i0 + 1] += gy0; grad_verts_ndc[3 * i0 + 2] += dz0;
+            grad_verts_ndc[3 * i1] += gx1; grad_verts_ndc[3 * i1 + 1] += gy1; grad_verts_ndc[3 * i1 + 2] += dz1;
+            grad_verts_ndc[3 * i2] += gx2; grad_verts_ndc[3 * i2 + 1] += gy2; grad_verts_ndc[3 * i2 + 2] += dz2;
+        }
+    }
+}
+
+/* backward of ref_project_verts w.r.t. the world vertices; grad_verts (V,3) accumulated */
+void ref_project_verts_bwd(const float *verts, int V, const float *R, const float *T, float s,
+                           const double *grad_ndc, double *grad_verts)
+{
+    for (int v = 0; v < V; ++v) {
+        const double x = verts[3 * v], y = verts[3 * v + 1], z = verts[3 * v + 2];
+        const double xv = x * R[0] + y * R[3] + z * R[6] + T[0];
+        const double yv = x * R[1] + y * R[4] + z * R[7] + T[1];
+        const double zv = x * R[2] + y * R[5] + z * R[8] + T[2];
+        const double gxn = grad_ndc[3 * v], gyn = grad_ndc[3 * v + 1], gz = grad_ndc[3 * v + 2];
+        const double dxv = s * gxn / zv, dyv = s * gyn / zv;
+        const double dzv = gz - s * (gxn * xv + gyn * yv) / (zv * zv);
+        grad_verts[3 * v + 0] += dxv * R[0] + dyv * R[1] + dzv * R[2];
+        grad_verts[3 * v + 1] += dxv * R[3] + dyv * R[4] + dzv * R[5];
+        grad_verts[3 * v + 2] += dxv * R[6] + dyv * R[7] + dzv * R[8];
+    }
+}

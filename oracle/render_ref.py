@@ -46,7 +46,11 @@ def lib():
                                        F64P, F32P]
         _lib.ref_adam_step.argtypes = [F32P, F32P, F32P, F32P, ctypes.c_size_t, ctypes.c_int,
                                        ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float]
-        for f in ("ref_project_verts", "ref_rasterize", "ref_shade_fwd", "ref_shade_bwd", "ref_adam_step"):
+        _lib.ref_uv_to_bary_grad.argtypes = [F32P, I32P, F32P, I32P, ctypes.c_int, F32P]
+        _lib.ref_raster_bwd.argtypes = [F32P, I32P, F32P, I32P, ctypes.c_int, F64P]
+        _lib.ref_project_verts_bwd.argtypes = [F32P, ctypes.c_int, F32P, F32P, ctypes.c_float, F64P, F64P]
+        for f in ("ref_project_verts", "ref_rasterize", "ref_shade_fwd", "ref_shade_bwd", "ref_adam_step",
+                  "ref_uv_to_bary_grad", "ref_raster_bwd", "ref_project_verts_bwd"):
             getattr(_lib, f).restype = None
     return _lib
 
@@ -204,3 +208,46 @@ def adam_step(p, g, m, v, step, lr=0.01, b1=0.9, b2=0.999, eps=1e-8):
     for a in (p, g, m, v):
         assert a.dtype == np.float32 and a.flags.c_contiguous
     lib().ref_adam_step(_p(p, F32P), _p(g, F32P), _p(m, F32P), _p(v, F32P), p.size, step, lr, b1, b2, eps)
+
+
+# ----------------------------------------------------------------------------- vertex path
+
+
+def uv_to_bary_grad(grad_uv, p2f, verts_uvs, faces_uvs):
+    S = p2f.shape[0]
+    out = np.empty((S, S, 3), np.float32)
+    grad_uv, verts_uvs, faces_uvs = _f32(grad_uv), _f32(verts_uvs), _i32(faces_uvs)
+    lib().ref_uv_to_bary_grad(_p(grad_uv, F32P), _p(p2f, I32P), _p(verts_uvs, F32P), _p(faces_uvs, I32P), S, _p(out, F32P))
+    return out
+
+
+def raster_bwd(grad_bary, p2f, verts_ndc, faces, grad_verts_ndc=None):
+    S = p2f.shape[0]
+    verts_ndc, faces, grad_bary = _f32(verts_ndc), _i32(faces), _f32(grad_bary)
+    if grad_verts_ndc is None:
+        grad_verts_ndc = np.zeros(verts_ndc.shape, np.float64)
+    lib().ref_raster_bwd(_p(grad_bary, F32P), _p(p2f, I32P), _p(verts_ndc, F32P), _p(faces, I32P), S, _p(grad_verts_ndc, F64P))
+    return grad_verts_ndc
+
+
+def project_verts_bwd(verts, R, T, grad_ndc, grad_verts=None):
+    verts, R, T = _f32(verts), _f32(R), _f32(T)
+    grad_ndc = np.ascontiguousarray(grad_ndc, dtype=np.float64)
+    if grad_verts is None:
+        grad_verts = np.zeros(verts.shape, np.float64)
+    lib().ref_project_verts_bwd(_p(verts, F32P), verts.shape[0], _p(R, F32P), _p(T, F32P), INV_TAN_HALF_FOV,
+                                _p(grad_ndc, F64P), _p(grad_verts, F64P))
+    return grad_verts
+
+
+def render_bwd_views(grad_imgs, frags, verts, faces, verts_uvs, faces_uvs, texture, R, T):
+    """d loss / d (texture, verts) for a batch of views given d loss / d images (B,3,S,S)."""
+    gtex = np.zeros(texture.shape, np.float64)
+    gverts = np.zeros(np.asarray(verts).shape, np.float64)
+    for b in range(R.shape[0]):
+        _, guv = shade_bwd(grad_imgs[b], frags[b], verts_uvs, faces_uvs, texture, gtex, want_uv=True)
+        gb = uv_to_bary_grad(guv, frags[b][0], verts_uvs, faces_uvs)
+        ndc = project_verts(verts, R[b], T[b])
+        gndc = raster_bwd(gb, frags[b][0], ndc, faces)
+        project_verts_bwd(verts, R[b], T[b], gndc, gverts)
+    return gtex, gverts
