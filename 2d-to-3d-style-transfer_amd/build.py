@@ -27,6 +27,7 @@ SOURCES = {
     "raster.hip": ["-ffp-contract=off"],
     "shade.hip": ["-ffp-contract=off"],
     "conv.hip": [],
+    "wino.hip": [],
     "gram.hip": [],
     "loss.hip": ["-ffp-contract=off"],
     "mesh.hip": [],

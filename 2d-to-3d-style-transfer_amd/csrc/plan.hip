@@ -7,6 +7,7 @@
 // optimised parameters (content features, style Grams: losses.py:18-25) is set once through
 // st3d_plan_set_content / st3d_plan_set_style.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include <vector>
 
@@ -62,20 +63,31 @@ int pool_slot(int module_idx) {
 }  // namespace
 
 struct st3d_vgg {
-    float *wf[16];
+    float *wf[16];     // direct implicit-GEMM packs (conv.hip)
     float *wd[16];
+    float *uf[16];     // Winograd packs (wino.hip), nullptr where the layer shape is not supported
+    float *ud[16];
     float *bias[16];
     bool set[16];
+    bool use_wino;     // ST3D_CONV=direct forces the direct kernels (A/B runs)
 };
 
 extern "C" int st3d_vgg_create(st3d_vgg **out) {
     ST3D_CHECK_ARG(out);
     st3d_vgg *v = new st3d_vgg();
     memset(v, 0, sizeof(*v));
+    const char *mode = getenv("ST3D_CONV");
+    v->use_wino = !(mode && strcmp(mode, "direct") == 0);
     for (int i = 0; i < 16; ++i) {
         const size_t n = st3d_conv3x3_packed_floats(kConvCout[i], kConvCin[i]);
-        if (hipMalloc(&v->wf[i], n * sizeof(float)) != hipSuccess || hipMalloc(&v->wd[i], n * sizeof(float)) != hipSuccess ||
-            hipMalloc(&v->bias[i], kConvCout[i] * sizeof(float)) != hipSuccess) {
+        bool ok = hipMalloc(&v->wf[i], n * sizeof(float)) == hipSuccess && hipMalloc(&v->wd[i], n * sizeof(float)) == hipSuccess &&
+                  hipMalloc(&v->bias[i], kConvCout[i] * sizeof(float)) == hipSuccess;
+        // both directions must be Winograd-able (dgrad swaps the channel roles)
+        if (ok && st3d_wino_supported(kConvCin[i], kConvCout[i], 2, 2) && st3d_wino_supported(kConvCout[i], kConvCin[i], 2, 2)) {
+            const size_t nu = st3d_wino_packed_floats(kConvCout[i], kConvCin[i]);
+            ok = hipMalloc(&v->uf[i], nu * sizeof(float)) == hipSuccess && hipMalloc(&v->ud[i], nu * sizeof(float)) == hipSuccess;
+        }
+        if (!ok) {
             st3d::set_error("st3d_vgg_create: hipMalloc failed");
             st3d_vgg_destroy(v);
             return ST3D_E_NOMEM;
@@ -90,6 +102,7 @@ extern "C" int st3d_vgg_set_conv(st3d_vgg *vgg, int module_idx, const float *w, 
     const int s = conv_slot(module_idx);
     ST3D_CHECK_ARG(s >= 0);
     ST3D_TRY(st3d_conv3x3_pack(w, kConvCout[s], kConvCin[s], vgg->wf[s], vgg->wd[s], stream));
+    if (vgg->uf[s]) ST3D_TRY(st3d_wino_pack(w, kConvCout[s], kConvCin[s], vgg->uf[s], vgg->ud[s], stream));
     ST3D_HIP(hipMemcpyAsync(vgg->bias[s], b, kConvCout[s] * sizeof(float), hipMemcpyDeviceToDevice, st3d::as_stream(stream)));
     vgg->set[s] = true;
     return ST3D_OK;
@@ -100,6 +113,8 @@ extern "C" int st3d_vgg_destroy(st3d_vgg *vgg) {
     for (int i = 0; i < 16; ++i) {
         if (vgg->wf[i]) (void)hipFree(vgg->wf[i]);
         if (vgg->wd[i]) (void)hipFree(vgg->wd[i]);
+        if (vgg->uf[i]) (void)hipFree(vgg->uf[i]);
+        if (vgg->ud[i]) (void)hipFree(vgg->ud[i]);
         if (vgg->bias[i]) (void)hipFree(vgg->bias[i]);
     }
     delete vgg;
@@ -172,7 +187,9 @@ enum { F_CONV_FWD = 0, F_CONV_DGRAD = 1, F_POOL = 2, F_GRAM_FWD = 3, F_GRAM_BWD 
 
 __global__ void combine_loss_kernel(float *loss, float sw, float cw) { loss[0] = cw * loss[1] + sw * loss[2]; }
 
-int forward(st3d_plan *p, const float *imgs, int n, int upto, hipStream_t s) {
+// keep_full: also materialise the full-resolution output of convs whose 2x2 pool is fused into
+// their epilogue (needed only when a caller asks for that activation: st3d_plan_forward).
+int forward(st3d_plan *p, const float *imgs, int n, int upto, bool keep_full, hipStream_t s) {
     const float *x = imgs;
     int Cin = 3, H = p->S, W = p->S;
     for (int m = 0; m <= upto; ++m) {
@@ -183,9 +200,26 @@ int forward(st3d_plan *p, const float *imgs, int n, int upto, hipStream_t s) {
                 return ST3D_E_STATE;
             }
             Scope sc(p, F_CONV_FWD, s);
-            ST3D_TRY(st3d_conv3x3_fwd(x, p->vgg->wf[cs], p->vgg->bias[cs], p->act[m], n, Cin, kConvCout[cs], H, W, 1, s));
-            x = p->act[m];
-            Cin = kConvCout[cs];
+            const bool wino = p->vgg->use_wino && p->vgg->uf[cs] && st3d_wino_supported(Cin, kConvCout[cs], H, W);
+            if (wino) {
+                const int pool_m = m + 2;          // conv, relu, pool
+                const int pps = (pool_m <= upto) ? pool_slot(pool_m) : -1;
+                float *yfull = (pps < 0 || keep_full) ? p->act[m] : nullptr;
+                ST3D_TRY(st3d_wino_fwd(x, p->vgg->uf[cs], p->vgg->bias[cs], yfull, pps >= 0 ? p->act[pool_m] : nullptr,
+                                       pps >= 0 ? p->pidx[pps] : nullptr, n, Cin, kConvCout[cs], H, W, 1, s));
+                Cin = kConvCout[cs];
+                if (pps >= 0) {                     // pool output produced by the conv epilogue: skip modules m+1, m+2
+                    x = p->act[pool_m];
+                    H /= 2; W /= 2;
+                    m = pool_m;
+                } else {
+                    x = p->act[m];
+                }
+            } else {
+                ST3D_TRY(st3d_conv3x3_fwd(x, p->vgg->wf[cs], p->vgg->bias[cs], p->act[m], n, Cin, kConvCout[cs], H, W, 1, s));
+                x = p->act[m];
+                Cin = kConvCout[cs];
+            }
         } else if (ps >= 0) {
             Scope sc(p, F_POOL, s);
             ST3D_TRY(st3d_maxpool2x2_fwd(x, p->act[m], p->pidx[ps], n, Cin, H, W, s));
@@ -273,7 +307,7 @@ extern "C" size_t st3d_plan_bytes(const st3d_plan *p) { return p ? p->bytes : 0;
 extern "C" int st3d_plan_forward(st3d_plan *p, const float *imgs, int n, int upto_module, st3d_stream_t stream) {
     ST3D_CHECK_ARG(p && imgs);
     ST3D_CHECK_ARG(n > 0 && n <= p->B && upto_module >= 0 && upto_module < kModules);
-    return forward(p, imgs, n, upto_module, st3d::as_stream(stream));
+    return forward(p, imgs, n, upto_module, true, st3d::as_stream(stream));
 }
 
 extern "C" int st3d_plan_activation(st3d_plan *p, int module_idx, float **ptr, int *C, int *H, int *W) {
@@ -288,7 +322,7 @@ extern "C" int st3d_plan_activation(st3d_plan *p, int module_idx, float **ptr, i
 extern "C" int st3d_plan_set_content(st3d_plan *p, const float *content, int n, st3d_stream_t stream) {
     ST3D_CHECK_ARG(p && content && n > 0 && n <= p->B);
     hipStream_t s = st3d::as_stream(stream);
-    ST3D_TRY(forward(p, content, n, kContentTap, s));
+    ST3D_TRY(forward(p, content, n, kContentTap, false, s));
     const size_t cnt = (size_t)n * p->C[kContentTap] * p->H[kContentTap] * p->W[kContentTap];
     ST3D_HIP(hipMemcpyAsync(p->content_target, p->act[kContentTap], cnt * sizeof(float), hipMemcpyDeviceToDevice, s));
     p->have_content = true;
@@ -298,7 +332,7 @@ extern "C" int st3d_plan_set_content(st3d_plan *p, const float *content, int n, 
 extern "C" int st3d_plan_set_style(st3d_plan *p, const float *style, int style_batch, int n, st3d_stream_t stream) {
     ST3D_CHECK_ARG(p && style && n > 0 && n <= p->B && (style_batch == 1 || style_batch == n));
     hipStream_t s = st3d::as_stream(stream);
-    ST3D_TRY(forward(p, style, style_batch, 28, s));
+    ST3D_TRY(forward(p, style, style_batch, 28, false, s));
     for (int i = 0; i < 5; ++i) {
         const int m = kStyleTap[i];
         Scope sc(p, F_GRAM_FWD, s);
@@ -320,7 +354,7 @@ extern "C" int st3d_plan_loss(st3d_plan *p, const float *current, int n, int bat
     }
     ST3D_CHECK_ARG(p->style_batch == 1 || p->style_batch == n);
     hipStream_t s = st3d::as_stream(stream);
-    ST3D_TRY(forward(p, current, n, 28, s));
+    ST3D_TRY(forward(p, current, n, 28, false, s));
     ST3D_HIP(hipMemsetAsync(loss_out, 0, 3 * sizeof(float), s));
 
     const double bd = (double)batch_denom;
@@ -379,11 +413,19 @@ extern "C" int st3d_plan_loss(st3d_plan *p, const float *current, int n, int bat
         float *dst = (cs == 0) ? grad_current : gn;
         {
             Scope sc(p, F_CONV_DGRAD, s);
+            const bool wino = p->vgg->use_wino && p->vgg->ud[cs] && st3d_wino_supported(kConvCout[cs], kConvCin[cs], H, W);
             if (g_is_pooled) {
-                ST3D_TRY(st3d_conv3x3_dgrad_unpool(g, p->pidx[pool_of_g], p->act[kPoolIdx[pool_of_g]], p->vgg->wd[cs], dst, n,
-                                                   kConvCin[cs], kConvCout[cs], H, W, s));
+                if (wino)
+                    ST3D_TRY(st3d_wino_dgrad_unpool(g, p->pidx[pool_of_g], p->act[kPoolIdx[pool_of_g]], p->vgg->ud[cs], dst, n,
+                                                    kConvCin[cs], kConvCout[cs], H, W, s));
+                else
+                    ST3D_TRY(st3d_conv3x3_dgrad_unpool(g, p->pidx[pool_of_g], p->act[kPoolIdx[pool_of_g]], p->vgg->wd[cs], dst,
+                                                       n, kConvCin[cs], kConvCout[cs], H, W, s));
             } else {
-                ST3D_TRY(st3d_conv3x3_dgrad(g, p->act[m], p->vgg->wd[cs], dst, n, kConvCin[cs], kConvCout[cs], H, W, s));
+                if (wino)
+                    ST3D_TRY(st3d_wino_dgrad(g, p->act[m], p->vgg->ud[cs], dst, n, kConvCin[cs], kConvCout[cs], H, W, s));
+                else
+                    ST3D_TRY(st3d_conv3x3_dgrad(g, p->act[m], p->vgg->wd[cs], dst, n, kConvCin[cs], kConvCout[cs], H, W, s));
             }
         }
         // dst is the gradient w.r.t. this conv's input: either the previous conv's post-ReLU

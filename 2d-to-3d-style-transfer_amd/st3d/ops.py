@@ -162,6 +162,44 @@ def conv3x3_dgrad_unpool(gy_pooled, pool_idx, pooled, wd, Cin):
     return gx
 
 
+def wino_pack(w):
+    """w (Cout,Cin,3,3) -> (u_fwd [16][Cin][Cout], u_dgrad [16][Cout][Cin]) flat tensors."""
+    w = _f32c(w)
+    Cout, Cin = w.shape[:2]
+    n = _lib.load().st3d_wino_packed_floats(Cout, Cin)
+    uf = torch.empty((n,), dtype=F32, device=w.device)
+    ud = torch.empty((n,), dtype=F32, device=w.device)
+    call("st3d_wino_pack", dptr(w), Cout, Cin, dptr(uf), dptr(ud), stream_ptr())
+    return uf, ud
+
+
+def wino_fwd(x, uf, bias, Cout, relu=True, pool=False, keep_full=True):
+    N, Cin, H, W = x.shape
+    y = torch.empty((N, Cout, H, W), dtype=F32, device=x.device) if (keep_full or not pool) else None
+    yp = torch.empty((N, Cout, H // 2, W // 2), dtype=F32, device=x.device) if pool else None
+    idx = torch.empty((N, Cout, H // 2, W // 2), dtype=U8, device=x.device) if pool else None
+    call("st3d_wino_fwd", dptr(x.contiguous(), F32), dptr(uf, F32), dptr(bias, F32) if bias is not None else None, dptr(y),
+         dptr(yp), dptr(idx), N, Cin, Cout, H, W, 1 if relu else 0, stream_ptr())
+    return (y, yp, idx) if pool else y
+
+
+def wino_dgrad(gy, act, ud, Cin):
+    N, Cout, H, W = gy.shape
+    gx = torch.empty((N, Cin, H, W), dtype=F32, device=gy.device)
+    call("st3d_wino_dgrad", dptr(gy.contiguous(), F32), dptr(act, F32) if act is not None else None, dptr(ud, F32),
+         dptr(gx), N, Cin, Cout, H, W, stream_ptr())
+    return gx
+
+
+def wino_dgrad_unpool(gy_pooled, pool_idx, pooled, ud, Cin):
+    N, Cout, Hp, Wp = gy_pooled.shape
+    H, W = 2 * Hp, 2 * Wp
+    gx = torch.empty((N, Cin, H, W), dtype=F32, device=gy_pooled.device)
+    call("st3d_wino_dgrad_unpool", dptr(gy_pooled.contiguous(), F32), dptr(pool_idx, U8), dptr(pooled, F32), dptr(ud, F32),
+         dptr(gx), N, Cin, Cout, H, W, stream_ptr())
+    return gx
+
+
 def maxpool2x2(y, want_idx=True):
     N, C, H, W = y.shape
     p = torch.empty((N, C, H // 2, W // 2), dtype=F32, device=y.device)

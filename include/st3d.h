@@ -121,6 +121,21 @@ int st3d_conv3x3_dgrad(const float *gy, const float *act, const float *w_dgrad_p
 int st3d_conv3x3_dgrad_unpool(const float *gy_pooled, const uint8_t *pool_idx, const float *pooled,
                               const float *w_dgrad_packed, float *gx, int N, int Cin, int Cout,
                               int H, int W, st3d_stream_t stream);
+/* Winograd F(2x2,3x3) variants of the three conv entry points above (exact-fp32 MFMA products,
+ * 2.25x fewer of them); for Cin >= 64, Cin % 4 == 0, Cout % 64 == 0, H and W even -- every VGG
+ * layer but conv1_1.  u_fwd = [16][Cin][Cout], u_dgrad = [16][Cout][Cin] (st3d_wino_pack).
+ * st3d_wino_fwd can fuse the following MaxPool2d(2,2): y_pooled (N,Cout,H/2,W/2) + pool_idx
+ * (either NULL = no pooling); y may then be NULL to skip the full-resolution store. */
+int st3d_wino_supported(int Cin, int Cout, int H, int W);
+size_t st3d_wino_packed_floats(int Cout, int Cin);
+int st3d_wino_pack(const float *w, int Cout, int Cin, float *u_fwd, float *u_dgrad, st3d_stream_t stream);
+int st3d_wino_fwd(const float *x, const float *u_fwd, const float *bias, float *y, float *y_pooled,
+                  uint8_t *pool_idx, int N, int Cin, int Cout, int H, int W, int relu, st3d_stream_t stream);
+int st3d_wino_dgrad(const float *gy, const float *act, const float *u_dgrad, float *gx, int N, int Cin,
+                    int Cout, int H, int W, st3d_stream_t stream);
+int st3d_wino_dgrad_unpool(const float *gy_pooled, const uint8_t *pool_idx, const float *pooled,
+                           const float *u_dgrad, float *gx, int N, int Cin, int Cout, int H, int W,
+                           st3d_stream_t stream);
 /* MaxPool2d(2,2): y (N,C,H,W) -> p (N,C,H/2,W/2) (+ argmax idx, may be NULL) */
 int st3d_maxpool2x2_fwd(const float *y, float *p, uint8_t *idx, int N, int C, int H, int W,
                         st3d_stream_t stream);

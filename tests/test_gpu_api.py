@@ -64,7 +64,8 @@ def test_get_features_fused_equals_generic_walk_and_oracle(mods, vgg, golden_dir
     ref = P.get_features_ref(torch.from_numpy(d["cur"]), P.make_vgg19_features(seed=0))
     for k in fused:
         assert float(fused[k].min()) == 0.0
-        torch.testing.assert_close(fused[k], generic[k], rtol=0, atol=0)       # same kernels, same bits
+        # fused = Winograd kernels, generic walk = direct kernels: same fp32 arithmetic class, different order
+        assert float((fused[k] - generic[k]).abs().max()) <= 5e-5 * float(generic[k].abs().max())
         scale = float(ref[k].abs().max())
         assert float((fused[k].cpu() - ref[k]).abs().max()) <= 2e-4 * scale
     # custom layer dict incl. a pool output and the unused tail (module 36)

@@ -319,3 +319,55 @@ def test_mesh_regularisers_match_oracle(dev, ops, cow):
     assert abs(out[0].item() - total.item()) <= 1e-5 * abs(total.item())
     rel = (grad.cpu().double() - vd.grad).norm() / vd.grad.norm()
     assert float(rel) <= 1e-4, float(rel)
+
+
+# ---------------------------------------------------------------------------- Winograd F(2x2,3x3) conv
+WINO_CASES = [(2, 64, 64, 64, 64), (1, 64, 128, 32, 32), (1, 128, 256, 24, 56), (1, 256, 256, 32, 32), (2, 512, 512, 16, 16),
+              (1, 512, 512, 4, 4), (1, 64, 64, 48, 40), (1, 128, 64, 10, 6)]
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W", WINO_CASES)
+def test_wino_fwd_dgrad(dev, ops, N, Cin, Cout, H, W):
+    """Winograd conv vs an fp64 direct convolution: within 3e-5 of the output scale (the transforms
+    add a few fp32 roundings per product; still fp32 products + fp32 accumulation)."""
+    torch.manual_seed(Cin + Cout + H)
+    x = torch.randn(N, Cin, H, W, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(Cout, Cin, 3, 3) * (2.0 / (Cin * 9)) ** 0.5).double()
+    b = (torch.randn(Cout) * 0.1).double()
+    y = F.relu(F.conv2d(x, w, b, padding=1))
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    uf, ud = ops.wino_pack(w.float().to(dev))
+    yd = ops.wino_fwd(x.detach().float().to(dev), uf, b.float().to(dev), Cout, relu=True)
+    _scale_close(yd, y, 3e-5, "wino fwd")
+    y_nr = ops.wino_fwd(x.detach().float().to(dev), uf, b.float().to(dev), Cout, relu=False)
+    _scale_close(y_nr, F.conv2d(x.detach(), w, b, padding=1), 3e-5, "wino fwd (no relu)")
+    gx = ops.wino_dgrad(gy.float().to(dev), yd, ud, Cin)
+    _scale_close(gx, x.grad, 5e-5, "wino dgrad")
+    # agreement with the direct MFMA kernel (different algorithm, same inputs)
+    wf, wd = ops.conv3x3_pack(w.float().to(dev))
+    _scale_close(yd, ops.conv3x3_fwd(x.detach().float().to(dev), wf, b.float().to(dev), Cout, relu=True), 3e-5, "wino vs direct")
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 64, 64, 32, 64), (1, 128, 128, 16, 16), (1, 256, 256, 8, 40)])
+def test_wino_fused_pool_and_unpool(dev, ops, N, Cin, Cout, H, W):
+    """conv -> ReLU -> MaxPool2d(2,2) fused in the Winograd epilogue (values + ATen's first-max argmax),
+    and the gradient back through pool + ReLU + conv in one kernel."""
+    torch.manual_seed(H * 3 + W)
+    x = torch.randn(N, Cin, H, W, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(Cout, Cin, 3, 3) * (2.0 / (Cin * 9)) ** 0.5).double()
+    b = (torch.randn(Cout) * 0.1).double()
+    y = F.relu(F.conv2d(x, w, b, padding=1))
+    p = F.max_pool2d(y, 2, 2)
+    gp = torch.randn_like(p)
+    p.backward(gp)
+    uf, ud = ops.wino_pack(w.float().to(dev))
+    yd, pd, idx = ops.wino_fwd(x.detach().float().to(dev), uf, b.float().to(dev), Cout, relu=True, pool=True)
+    _scale_close(yd, y, 3e-5, "wino fwd")
+    p2, idx2 = ops.maxpool2x2(yd)
+    assert torch.equal(pd, p2) and torch.equal(idx, idx2)          # fused pool == separate pool kernel on the same values
+    none_full, pd3, idx3 = ops.wino_fwd(x.detach().float().to(dev), uf, b.float().to(dev), Cout, relu=True, pool=True,
+                                        keep_full=False)
+    assert none_full is None and torch.equal(pd3, pd) and torch.equal(idx3, idx)
+    gx = ops.wino_dgrad_unpool(gp.float().to(dev), idx, pd, ud, Cin)
+    _scale_close(gx, x.grad, 6e-5, "wino dgrad_unpool")
