@@ -27,7 +27,7 @@ SOURCES = {
     "raster.hip": ["-ffp-contract=off"],
     "shade.hip": ["-ffp-contract=off"],
     "conv.hip": [],
-    "wino.hip": [],
+    "wino.hip": ["-fno-slp-vectorize"],   # SLP-packed f32 (v_pk_*) needs register shuffles that cost matrix-pipe time
     "gram.hip": [],
     "loss.hip": ["-ffp-contract=off"],
     "mesh.hip": [],

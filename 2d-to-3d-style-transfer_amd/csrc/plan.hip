@@ -83,7 +83,7 @@ extern "C" int st3d_vgg_create(st3d_vgg **out) {
         bool ok = hipMalloc(&v->wf[i], n * sizeof(float)) == hipSuccess && hipMalloc(&v->wd[i], n * sizeof(float)) == hipSuccess &&
                   hipMalloc(&v->bias[i], kConvCout[i] * sizeof(float)) == hipSuccess;
         // both directions must be Winograd-able (dgrad swaps the channel roles)
-        if (ok && st3d_wino_supported(kConvCin[i], kConvCout[i], 2, 2) && st3d_wino_supported(kConvCout[i], kConvCin[i], 2, 2)) {
+        if (ok && st3d_wino_supported(kConvCin[i], kConvCout[i], 4, 4) && st3d_wino_supported(kConvCout[i], kConvCin[i], 4, 4)) {
             const size_t nu = st3d_wino_packed_floats(kConvCout[i], kConvCin[i]);
             ok = hipMalloc(&v->uf[i], nu * sizeof(float)) == hipSuccess && hipMalloc(&v->ud[i], nu * sizeof(float)) == hipSuccess;
         }

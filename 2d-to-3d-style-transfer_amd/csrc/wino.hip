@@ -16,14 +16,19 @@
 // registers and along a through ONE [4][64][64] LDS exchange per output column; after it a lane
 // owns a whole 2x2 output tile, which IS the MaxPool2d(2,2) window, so pooling (+argmax) fuses
 // into the epilogue for free and the stores are one cout row (64 tiles) per wave instruction.
-// K loop: chunks of 4 input channels; per chunk U [16][4][64] (16 KB) and the patch
-// [4][10][34] are staged global->registers->LDS two chunks ahead (triple-buffered), the
-// input transform of chunk c+1 (patch -> V, one (tile, channel, row-half) per thread,
-// ds_read_b64 / ds_write_b32 conflict-free) runs beside the MFMAs of chunk c (double-buffered
-// V): one barrier per chunk.  The ReLU gate / 2x2 max-unpool of the backward pass are fused into
-// the patch load exactly as in conv.hip.  The cout-tile index is the fastest grid dimension so
-// the workgroups of one XCD (dispatch is round-robin over the 8 XCDs) stream the same U slice
-// out of that XCD's L2.
+// K loop: chunks of 4 input channels.  Each Winograd-domain filter element is consumed by exactly
+// one wave, so U never touches LDS: the pack stores every lane's 8 A operands of a chunk
+// contiguously and the wave fetches them one chunk ahead with two coalesced dwordx4 loads.
+// The haloed patch [4][10][34] is staged global->registers->LDS two chunks ahead
+// (triple-buffered), the input transform of chunk c+1 (patch -> V, one (tile, channel,
+// row-half) per thread, ds_read_b64 / ds_write_b32) runs beside the MFMAs of chunk c
+// (double-buffered V, n-tile pairs interleaved so one ds_read_b64 yields both B operands):
+// one barrier per chunk; the two waves of a SIMD run the chunk's phases in opposite order
+// (stagger).  The ReLU gate / 2x2 max-unpool of the backward pass are fused into the patch load
+// exactly as in conv.hip.  The cout-tile index is the fastest grid dimension so the workgroups
+// of one XCD (dispatch is round-robin over the 8 XCDs) stream the same U slice from that XCD's L2.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -32,43 +37,49 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int KC = 4;                 // input channels per chunk
+constexpr int KC = 4;                 // input channels per MFMA sub-chunk (2 k-steps of 2)
+constexpr int KS = 8;                 // input channels staged per barrier (2 sub-chunks)
 constexpr int BCO = 64;               // cout per workgroup
 constexpr int TROWS = 8, TCOLS = 32;  // output pixels per workgroup
 constexpr int NT = 512;               // threads per workgroup (8 waves, 2 per SIMD)
-constexpr int PR = TROWS + 2, PC = TCOLS + 2, PS = PR * PC;   // haloed patch per channel
-constexpr int P_ELEMS = KC * PS;                               // 1360
-constexpr int P_PER_T = (P_ELEMS + NT - 1) / NT;               // 3
-constexpr int P_PAD = P_PER_T * NT;                            // 1536
-constexpr int U_ELEMS = 16 * KC * BCO;                         // 4096 floats = 1024 float4 = 2 per thread
-constexpr int V_ELEMS = 16 * KC * 64;                          // 4096
-constexpr int SMEM_FLOATS = 3 * U_ELEMS + 3 * P_PAD + 2 * V_ELEMS;   // 25088 floats = 98 KB
-static_assert(SMEM_FLOATS >= 4 * 64 * 64, "the epilogue exchange needs [4][64][64] floats");
+constexpr int PR = TROWS + 2, PC = TCOLS + 2;    // haloed patch: 10 rows x 34 columns per channel
+constexpr int PCP = 48;                          // LDS row pitch: 2 rows apart = 96 words = 32 banks (mod 64),
+                                                 // so the two tile rows of a half-wave never share a bank
+constexpr int PS = PR * PCP;                     // 480 floats per channel
+constexpr int P_STAGE = KS * PS + 8;             // 3848 floats = 15 KB per stage (+4 leading, +4 trailing floats of slack)
+constexpr int EX_FLOATS = 4 * 64 * 64;           // epilogue exchange [4 a][64 co][64 tiles]
+constexpr int LOOP_FLOATS = 3 * P_STAGE;
+constexpr int SMEM_FLOATS = EX_FLOATS > LOOP_FLOATS ? EX_FLOATS : LOOP_FLOATS;   // 64 KB
 
 struct WinoArgs {
     const float *x;       // MODE 0/1: (N,Cin,H,W); MODE 2: pooled-resolution gradient (N,Cin,H/2,W/2)
     const float *aux;     // MODE 1: saved post-ReLU activation; MODE 2: pooled values
     const uint8_t *idx;   // MODE 2: pool argmax
-    const float *U;       // [16][Cin][Cout]
+    const float *U;       // packed [ct][chunk][wave 8][lane 64][ks 2][q 4]  (see wino_pack_kernel)
     const float *bias;    // (Cout) or nullptr
     float *y;             // (N,Cout,H,W) or nullptr (EPI 1 may skip the full-resolution store)
     float *yp;            // EPI 1: pooled output (N,Cout,H/2,W/2)
     uint8_t *yidx;        // EPI 1: argmax
     int N, Cin, Cout, H, W, relu, tiles_x, tiles_y, n_ct;
+    unsigned long long *dbg;   // diagnostic builds only (DBG != 0): per-wave phase cycle sums
 };
 
 // Wave roles (8 waves): a = wave & 3 is the row of the 4x4 Winograd domain the wave accumulates
 // (xi = 4a .. 4a+3), mh = wave >> 2 the 32-cout half; every wave covers all 64 tiles (2 MFMA
-// n-tiles).  8 MFMA tiles = 128 accumulator VGPRs per wave -> two waves per SIMD, which hides the
-// LDS-operand latency and the barrier bubbles of each other.  Per k-step a wave reads 4 A + 8 B
-// dwords for 8 MFMAs.  The output transform runs along b inside the wave (registers) and along a
-// across the four a-waves through one [4][64][64] LDS exchange per output column j.
-template <int MODE, int EPI>
+// n-tiles): 8 MFMA tiles = 128 accumulator VGPRs per wave, two waves per SIMD.
+//  * A operands (U): each element is consumed by exactly ONE wave, so U never touches LDS; the
+//    pack stores every lane's 8 operands of a sub-chunk contiguously (two coalesced dwordx4
+//    loads, issued one sub-chunk ahead).
+//  * B operands (V = B^T d B): a lane computes ITS OWN four operands (b = 0..3 of the wave's row
+//    a) for its (tile, channel) straight from the staged patch: 2 patch rows x 4 columns
+//    (ds_read_b64 x 4), one fma + one add/sub each.  V is never written to LDS, so the only
+//    cross-wave dependency is the patch itself, staged 8 channels per barrier two stages ahead
+//    (triple buffer), and a wave fetches the patch rows of the NEXT sub-chunk -- across the
+//    barrier too -- while the MFMAs of the current one run: no LDS latency behind a barrier.
+template <int MODE, int EPI, int DBG = 0>
 __global__ __launch_bounds__(NT, 2) void wino_kernel(const WinoArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
-    float *sU = smem;                          // [3][U_ELEMS]
-    float *sP = smem + 3 * U_ELEMS;            // [3][P_PAD]
-    float *sV = sP + 3 * P_PAD;                // [2][V_ELEMS]
+    float *sP = smem;                          // [3][KS][PR][PCP]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -86,93 +97,133 @@ __global__ __launch_bounds__(NT, 2) void wino_kernel(const WinoArgs a) {
     const size_t HW = (size_t)H * W;
     const int Hp = H >> 1, Wp = W >> 1;
     const size_t in_plane = (MODE == 2) ? (size_t)Hp * Wp : HW;
+    const int nstages = a.Cin / KS;
 
-    // ---- per-thread patch coordinates
-    int xoff[P_PER_T];
-    unsigned xvalid = 0;
-    unsigned xpos[MODE == 2 ? P_PER_T : 1];
+    // ---- staging.  One item = 4 consecutive columns of one patch row of one channel, fetched
+    // with ONE 16-byte load: 10 rows x 10 items (columns x0-4 .. x0+35, 16-B aligned) x 8
+    // channels = 800 items per stage, two per thread.  Vector-memory instructions are the scarce
+    // resource of this loop (~12 issue cycles each, shared by the CU's 8 waves), so the patch
+    // is loaded wide and written to LDS narrow (4 ds_write_b32: the patch origin x0-1 is odd).
+    // The global address is a constant per-item byte offset + a SCALAR per-stage offset through
+    // a buffer descriptor: no vector ALU work per load (f32 MFMAs do not co-issue with VALU, so
+    // every VALU instruction in this loop is paid in matrix-pipe time).  Items outside the image
+    // (W % 4 == 0: a whole item is inside or outside) use an offset beyond num_records and read
+    // 0 = the convolution's zero padding.
+    constexpr int ITEMS = KS * PR * 10, IPT = 2;
+    const unsigned kOob = 0x80000000u;
+    unsigned voff[IPT];        // byte offset inside the image (channel included)
+    int loff[IPT];             // LDS float offset of the item's first column (may be 3 floats before the row)
+    unsigned rowbit[MODE == 2 ? IPT : 1];
 #pragma unroll
-    for (int i = 0; i < P_PER_T; ++i) {
+    for (int i = 0; i < IPT; ++i) {
         const int e = tid + i * NT;
-        const int ci = e / PS, rem = e - ci * PS;
-        const int r = rem / PC, cc = rem - r * PC;
-        const int gy = y0 + r - 1, gx = x0 + cc - 1;
-        const bool ok = (e < P_ELEMS) && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        if (ok) xvalid |= 1u << i;
+        const int ci = e / 100, rem = e - ci * 100;
+        const int r = rem / 10, l = rem - r * 10;
+        const int gy = y0 + r - 1, gx0 = x0 - 4 + 4 * l;
+        const bool ok = e < ITEMS && gy >= 0 && gy < H && gx0 >= 0 && gx0 < W;
         if (MODE == 2) {
-            xoff[i] = ok ? (int)(ci * in_plane + (size_t)(gy >> 1) * Wp + (gx >> 1)) : 0;
-            xpos[i] = ((gy & 1) << 1) | (gx & 1);
+            voff[i] = ok ? (unsigned)((ci * in_plane + (size_t)(gy >> 1) * Wp + (gx0 >> 1)) * 4) : kOob;
+            rowbit[i] = (gy & 1) << 1;
         } else {
-            xoff[i] = ok ? (int)(ci * in_plane + (size_t)gy * W + gx) : 0;
+            voff[i] = ok ? (unsigned)((ci * in_plane + (size_t)gy * W + gx0) * 4) : kOob;
         }
+        loff[i] = (e < ITEMS) ? (4 + ci * PS + r * PCP + 4 * l - 3) : -1;     // +4: room for the first row's columns -3..-1
     }
-    const float *xin = a.x + (size_t)n * a.Cin * in_plane;
-    const float *auxin = (MODE != 0) ? a.aux + (size_t)n * a.Cin * in_plane : nullptr;
-    const uint8_t *idxin = (MODE == 2) ? a.idx + (size_t)n * a.Cin * in_plane : nullptr;
+    const unsigned img_bytes = (unsigned)((size_t)a.Cin * in_plane * 4);
+    const unsigned stage_bytes = (unsigned)(KS * in_plane * 4);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.x + (size_t)n * a.Cin * in_plane), 0, img_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t raux = rx, ridx = rx;
+    if (MODE != 0)
+        raux = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.aux + (size_t)n * a.Cin * in_plane), 0, img_bytes, 0x00020000);
+    if (MODE == 2)
+        ridx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.idx + (size_t)n * a.Cin * in_plane), 0, img_bytes / 4, 0x00020000);
+    // this lane's A operands of sub-chunk s: 8 floats (32 B) at byte offset uvoff + s * 16384
+    const int nsub = a.Cin / KC;
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.U + (size_t)ct * nsub * 4096), 0, (unsigned)((size_t)nsub * 4096 * 4), 0x00020000);
+    const unsigned uvoff = (unsigned)((wave * 64 + lane) * 32);
 
-    float xv[P_PER_T];
-    float xa[MODE != 0 ? P_PER_T : 1];
-    unsigned char xi[MODE == 2 ? P_PER_T : 1];
-    f32x4 uv[2];
+    // MODE 0/1: xv = 4 gradient/activation columns, xa = 4 gate columns (MODE 1)
+    // MODE 2  : xv[0..1] = 2 pooled-resolution gradients, xa[0..1] = 2 pooled values, xi = 2 argmax bytes
+    f32x4 xv[IPT];
+    f32x4 xa[MODE == 1 ? IPT : 1];
+    f32x2 xg[MODE == 2 ? IPT : 1], xp[MODE == 2 ? IPT : 1];
+    unsigned xi[MODE == 2 ? IPT : 1];
 
-    auto gload = [&](int c) __attribute__((always_inline)) {
-        const int ci0 = c * KC;
-        const size_t cbase = (size_t)ci0 * in_plane;
+    auto gload = [&](int st) __attribute__((always_inline)) {
+        const unsigned so = (unsigned)st * stage_bytes;
 #pragma unroll
-        for (int i = 0; i < P_PER_T; ++i) {
-            const size_t o = ((xvalid >> i) & 1u) ? cbase + xoff[i] : 0;
-            xv[i] = xin[o];
-            if (MODE != 0) xa[i] = auxin[o];
-            if (MODE == 2) xi[i] = idxin[o];
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int e4 = tid + i * NT, row = e4 >> 4, c4 = e4 & 15;
-            const int xi_ = row >> 2, k = row & 3;
-            uv[i] = *reinterpret_cast<const f32x4 *>(a.U + ((size_t)(xi_ * a.Cin + ci0 + k) * a.Cout + co0 + c4 * 4));
+        for (int i = 0; i < IPT; ++i) {
+            if (MODE == 2) {
+                xg[i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rx, voff[i], so, 0));
+                xp[i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(raux, voff[i], so, 0));
+                xi[i] = __builtin_amdgcn_raw_buffer_load_b16(ridx, voff[i] == kOob ? kOob : voff[i] / 4, so / 4, 0);
+            } else {
+                xv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff[i], so, 0));
+                if (MODE == 1) xa[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(raux, voff[i], so, 0));
+            }
         }
     };
     auto lstore = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < P_PER_T; ++i) {
-            bool ok = (xvalid >> i) & 1u;
-            if (MODE != 0) ok = ok && (xa[i] > 0.f);
-            if (MODE == 2) ok = ok && (xi[i] == xpos[i]);
-            sP[buf * P_PAD + tid + i * NT] = ok ? xv[i] : 0.f;
-        }
+        for (int i = 0; i < IPT; ++i) {
+            if (loff[i] >= 0) {
+                float *dst = &sP[buf * P_STAGE + loff[i]];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4 *>(&sU[buf * U_ELEMS + (tid + i * NT) * 4]) = uv[i];
+                for (int j = 0; j < 4; ++j) {
+                    float v;
+                    if (MODE == 0) v = xv[i][j];
+                    if (MODE == 1) v = (xa[i][j] > 0.f) ? xv[i][j] : 0.f;
+                    if (MODE == 2) {
+                        const unsigned ib = (xi[i] >> (8 * (j >> 1))) & 0xffu;
+                        v = (xp[i][j >> 1] > 0.f && ib == (rowbit[i] | (j & 1))) ? xg[i][j >> 1] : 0.f;
+                    }
+                    dst[j] = v;
+                }
+            }
+        }
     };
-    // input transform V = B^T d B: thread = (channel k = wave & 3, rows i in {2*rh, 2*rh+1} with
-    // rh = wave >> 2, tile t = lane)
-    const int tk = wave & 3, rh = wave >> 2;
-    const int tty = lane >> 4, ttx = lane & 15;
-    auto transform = [&](int pbuf, int vbuf) __attribute__((always_inline)) {
-        // rows d[rh], d[rh+1], d[rh+2] of the 4x4 patch (rh = 0: d0,d1,d2; rh = 1: d1,d2,d3)
-        const float *p = &sP[pbuf * P_PAD + tk * PS + (2 * tty + rh) * PC + 2 * ttx];
-        float d[3][4];
+
+    // B operands.  Row transform of the wave's row a: t = d[r1] + sg * d[r2]
+    //   a = 0: d0 - d2 ; a = 1: d1 + d2 ; a = 2: d2 - d1 ; a = 3: d1 - d3
+    const int r1 = (wa == 0) ? 0 : (wa == 2 ? 2 : 1);
+    const int r2 = (wa == 3) ? 3 : (wa == 2 ? 1 : 2);
+    const float sg = (wa == 1) ? 1.f : -1.f;
+    // lane -> (tile row within the n-tile, tile column, channel parity)
+    const int lane_off = lhi * PS + (2 * (l31 >> 4)) * PCP + 2 * (l31 & 15);
+    const int off1 = lane_off + r1 * PCP, off2 = lane_off + r2 * PCP;
+    // raw patch rows of one sub-chunk: [ks][nn][row 1/2][4 columns]
+    struct Raw { f32x2 v[2][2][2][2]; };
+    auto pread = [&](int buf, int sub, Raw &d) __attribute__((always_inline)) {
+        const float *p = &sP[buf * P_STAGE + 4 + sub * KC * PS];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const f32x2 lo = *reinterpret_cast<const f32x2 *>(p + r * PC);
-            const f32x2 hi = *reinterpret_cast<const f32x2 *>(p + r * PC + 2);
-            d[r][0] = lo[0]; d[r][1] = lo[1]; d[r][2] = hi[0]; d[r][3] = hi[1];
-        }
-        float t[2][4];
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            // rh = 0: t0 = d0 - d2, t1 = d1 + d2 ; rh = 1: t2 = d2 - d1, t3 = d1 - d3 (d1,d2,d3 = d[0],d[1],d[2])
-            t[0][j] = rh == 0 ? d[0][j] - d[2][j] : d[1][j] - d[0][j];
-            t[1][j] = rh == 0 ? d[1][j] + d[2][j] : d[0][j] - d[2][j];
-        }
-        float *v = &sV[vbuf * V_ELEMS + tk * 64 + lane];
+            for (int nn = 0; nn < 2; ++nn) {
+                const float *q1 = p + off1 + (2 * ks) * PS + (4 * nn) * PCP;
+                const float *q2 = p + off2 + (2 * ks) * PS + (4 * nn) * PCP;
+                d.v[ks][nn][0][0] = *reinterpret_cast<const f32x2 *>(q1);
+                d.v[ks][nn][0][1] = *reinterpret_cast<const f32x2 *>(q1 + 2);
+                d.v[ks][nn][1][0] = *reinterpret_cast<const f32x2 *>(q2);
+                d.v[ks][nn][1][1] = *reinterpret_cast<const f32x2 *>(q2 + 2);
+            }
+    };
+    struct Bop { float v[2][2][4]; };      // [ks][nn][q = b]
+    auto bcompute = [&](const Raw &d, Bop &bv) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = 2 * rh + i;
-            v[((row * 4 + 0) * KC) * 64] = t[i][0] - t[i][2];
-            v[((row * 4 + 1) * KC) * 64] = t[i][1] + t[i][2];
-            v[((row * 4 + 2) * KC) * 64] = t[i][2] - t[i][1];
-            v[((row * 4 + 3) * KC) * 64] = t[i][1] - t[i][3];
-        }
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int nn = 0; nn < 2; ++nn) {
+                const float t0 = d.v[ks][nn][0][0][0] + sg * d.v[ks][nn][1][0][0];
+                const float t1 = d.v[ks][nn][0][0][1] + sg * d.v[ks][nn][1][0][1];
+                const float t2 = d.v[ks][nn][0][1][0] + sg * d.v[ks][nn][1][1][0];
+                const float t3 = d.v[ks][nn][0][1][1] + sg * d.v[ks][nn][1][1][1];
+                bv.v[ks][nn][0] = t0 - t2;
+                bv.v[ks][nn][1] = t1 + t2;
+                bv.v[ks][nn][2] = t2 - t1;
+                bv.v[ks][nn][3] = t1 - t3;
+            }
     };
 
     f32x16 acc[4][2];      // [b][n]
@@ -183,37 +234,109 @@ __global__ __launch_bounds__(NT, 2) void wino_kernel(const WinoArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[q][nn][r] = 0.f;
 
-    const int nchunks = a.Cin / KC;
+    // Waves w and w+4 share a SIMD.  Running the same program they would reach their MFMA bursts,
+    // their staging work and the barrier together and the matrix pipe would idle through every
+    // non-MFMA phase, so the halves are STAGGERED: waves 0-3 ("A") stage (global loads at the top,
+    // LDS stores at the bottom) around their MFMAs, waves 4-7 ("B") store at the top what they
+    // loaded during the previous stage.  Both do the same work between two barriers.
+    const bool isA = __builtin_amdgcn_readfirstlane(wave) < 4;
     gload(0);
     lstore(0);
+    gload(nstages > 1 ? 1 : 0);
+    lstore(1);
+    if (!isA) gload(min(2, nstages - 1));      // B holds stage c+2 in registers across the barrier
+    auto uload = [&](int sub, f32x4 &u0, f32x4 &u1) __attribute__((always_inline)) {
+        const unsigned so = (unsigned)min(sub, nsub - 1) * 16384u;
+        u0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, uvoff, so, 0));
+        u1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, uvoff + 16, so, 0));
+    };
+    f32x4 ua0, ua1;
+    uload(0, ua0, ua1);
     __syncthreads();
-    if (nchunks > 1) gload(1);
-    transform(0, 0);
-    if (nchunks > 1) lstore(1);
-    __syncthreads();
+    Raw draw;
+    Bop bcur, bnext;
+    pread(0, 0, draw);
+    bcompute(draw, bcur);
 
-    int ub = 0, vb = 0;       // U/patch buffer of chunk c (mod 3), V buffer of chunk c (mod 2)
-    for (int c = 0; c < nchunks; ++c) {
-        const int ub1 = (ub == 2) ? 0 : ub + 1, ub2 = (ub1 == 2) ? 0 : ub1 + 1;
-        if (c + 2 < nchunks) gload(c + 2);
-        const float *pu = &sU[ub * U_ELEMS + ((wa * 4) * KC + lhi) * 64 + mh * 32 + l31];
-        const float *pv = &sV[vb * V_ELEMS + ((wa * 4) * KC + lhi) * 64 + l31];
-#pragma unroll
-        for (int ks = 0; ks < KC / 2; ++ks) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float av = pu[(q * KC + ks * 2) * 64];
-                const float b0 = pv[(q * KC + ks * 2) * 64];
-                const float b1 = pv[(q * KC + ks * 2) * 64 + 32];
-                acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[q][0], 0, 0, 0);
-                acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[q][1], 0, 0, 0);
-            }
+#define WINO_MFMA(ua, bv, ks, q)                                                                      \
+        acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[q], bv.v[ks][0][q], acc[q][0], 0, 0, 0);   \
+        acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[q], bv.v[ks][1][q], acc[q][1], 0, 0, 0);
+#define WINO_ULOAD(s_, u0, u1) f32x4 u0, u1; uload((s_), u0, u1);
+    // One stage = 8 input channels = sub-chunks s0 (operands in bcur/ua) and s1.  ONE basic block
+    // per stage with the order pinned (in-order issue: what should overlap a wave's own MFMAs
+    // must sit between them in program order).  Tail stages redo clamped, harmless work.
+    int pb = 0;            // patch buffer of stage c (mod 3)
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+    if (DBG) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast) :: "memory"); }
+#define STAMP(k) if (DBG) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); tsum[k] += t_ - tlast; tlast = t_; }
+    // Per stage each wave alternates four 8-MFMA bursts (M) with four overhead slots (O); a wave
+    // issues in order, so while it sits in a burst nothing else of it issues, and while it is in
+    // an overhead slot the matrix pipe is free for its partner.  A starts with a burst (its
+    // operands were prepared before the barrier), B with an overhead slot:
+    //   A:  M1 | O  | M2 | O  | M3 | O  | M4 | O  | barrier
+    //   B:  O  | M1 | O  | M2 | O  | M3 | O  | M4 | barrier
+    if (isA) {
+        for (int c = 0; c < nstages; ++c) {
+            const int pb1 = (pb == 2) ? 0 : pb + 1, pb2 = (pb1 == 2) ? 0 : pb1 + 1;
+            STAMP(0)
+            WINO_MFMA(ua0, bcur, 0, 0) WINO_MFMA(ua0, bcur, 0, 1) WINO_MFMA(ua0, bcur, 0, 2) WINO_MFMA(ua0, bcur, 0, 3)
+            __builtin_amdgcn_sched_barrier(0);
+            STAMP(1)
+            gload(min(c + 2, nstages - 1));
+            WINO_ULOAD(2 * c + 1, ub0, ub1)
+            pread(pb, 1, draw);
+            __builtin_amdgcn_sched_barrier(0);
+            STAMP(2)
+            WINO_MFMA(ua1, bcur, 1, 0) WINO_MFMA(ua1, bcur, 1, 1) WINO_MFMA(ua1, bcur, 1, 2) WINO_MFMA(ua1, bcur, 1, 3)
+            __builtin_amdgcn_sched_barrier(0);
+            STAMP(3)
+            bcompute(draw, bnext);
+            __builtin_amdgcn_sched_barrier(0);
+            WINO_MFMA(ub0, bnext, 0, 0) WINO_MFMA(ub0, bnext, 0, 1) WINO_MFMA(ub0, bnext, 0, 2) WINO_MFMA(ub0, bnext, 0, 3)
+            __builtin_amdgcn_sched_barrier(0);
+            STAMP(4)
+            uload(2 * c + 2, ua0, ua1);
+            pread(pb1, 0, draw);           // first sub-chunk of the NEXT stage (staged one barrier ago)
+            __builtin_amdgcn_sched_barrier(0);
+            WINO_MFMA(ub1, bnext, 1, 0) WINO_MFMA(ub1, bnext, 1, 1) WINO_MFMA(ub1, bnext, 1, 2) WINO_MFMA(ub1, bnext, 1, 3)
+            __builtin_amdgcn_sched_barrier(0);
+            STAMP(5)
+            bcompute(draw, bcur);
+            lstore(pb2);
+            STAMP(6)
+            __syncthreads();
+            STAMP(7)
+            pb = pb1;
         }
-        if (c + 1 < nchunks) transform(ub1, vb ^ 1);
-        if (c + 2 < nchunks) lstore(ub2);
-        __syncthreads();
-        ub = ub1; vb ^= 1;
+    } else {
+        for (int c = 0; c < nstages; ++c) {
+            const int pb1 = (pb == 2) ? 0 : pb + 1, pb2 = (pb1 == 2) ? 0 : pb1 + 1;
+            lstore(pb2);                                    // stage c+2, loaded during stage c-1
+            gload(min(c + 3, nstages - 1));
+            WINO_ULOAD(2 * c + 1, ub0, ub1)
+            pread(pb, 1, draw);
+            __builtin_amdgcn_sched_barrier(0);
+            WINO_MFMA(ua0, bcur, 0, 0) WINO_MFMA(ua0, bcur, 0, 1) WINO_MFMA(ua0, bcur, 0, 2) WINO_MFMA(ua0, bcur, 0, 3)
+            __builtin_amdgcn_sched_barrier(0);
+            bcompute(draw, bnext);
+            __builtin_amdgcn_sched_barrier(0);
+            WINO_MFMA(ua1, bcur, 1, 0) WINO_MFMA(ua1, bcur, 1, 1) WINO_MFMA(ua1, bcur, 1, 2) WINO_MFMA(ua1, bcur, 1, 3)
+            __builtin_amdgcn_sched_barrier(0);
+            uload(2 * c + 2, ua0, ua1);
+            pread(pb1, 0, draw);
+            __builtin_amdgcn_sched_barrier(0);
+            WINO_MFMA(ub0, bnext, 0, 0) WINO_MFMA(ub0, bnext, 0, 1) WINO_MFMA(ub0, bnext, 0, 2) WINO_MFMA(ub0, bnext, 0, 3)
+            __builtin_amdgcn_sched_barrier(0);
+            bcompute(draw, bcur);
+            __builtin_amdgcn_sched_barrier(0);
+            WINO_MFMA(ub1, bnext, 1, 0) WINO_MFMA(ub1, bnext, 1, 1) WINO_MFMA(ub1, bnext, 1, 2) WINO_MFMA(ub1, bnext, 1, 3)
+            __syncthreads();
+            pb = pb1;
+        }
     }
+#undef WINO_MFMA
+#undef WINO_ULOAD
+    if (DBG && a.dbg && blockIdx.x == 300 && lane == 0) { for (int k = 0; k < 8; ++k) a.dbg[wave * 8 + k] = tsum[k]; }
 
     // ---- epilogue: Y = A^T M A.  Along b in registers (z_j), along a through LDS.
     //   z_0 = m_a0 + m_a1 + m_a2 ; z_1 = m_a1 - m_a2 - m_a3      (this wave's row a)
@@ -273,8 +396,18 @@ __global__ __launch_bounds__(NT, 2) void wino_kernel(const WinoArgs a) {
     }
 }
 
-// w (Cout,Cin,3,3) -> U_fwd [16][Cin][Cout] = G g G^T and U_dgrad [16][Cout][Cin] = G g' G^T with
-// g'[ky][kx] = w[co][ci][2-ky][2-kx] (transposed convolution); computed in fp64, stored fp32.
+// w (Cout,Cin,3,3) -> Winograd-domain filters U = G g G^T (fp64, stored fp32), forward and
+// transposed (g'[ky][kx] = w[co][ci][2-ky][2-kx], channel roles swapped), laid out as the
+// MFMA A operands of wino_kernel: for GEMM (M = out channel m, K = in channel k, xi):
+//   [ct = m/64][chunk = k/4][wave = (xi>>2) + 4*((m%64)/32)][lane = (m%32) + 32*(k&1)][ks = (k%4)>>1][q = xi&3]
+// so a lane's 8 operands of a chunk are 32 contiguous bytes and a wave's are 2 KB.
+__device__ __forceinline__ size_t upack_index(int m, int k, int xi, int K) {
+    const int ct = m >> 6, col = m & 63, mh = col >> 5, l31 = col & 31;
+    const int chunk = k >> 2, kk = k & 3, lhi = kk & 1, ks = kk >> 1;
+    const int wave = (xi >> 2) + 4 * mh, lane = l31 + 32 * lhi;
+    return ((((size_t)ct * (K >> 2) + chunk) * 8 + wave) * 64 + lane) * 8 + ks * 4 + (xi & 3);
+}
+
 __global__ void wino_pack_kernel(const float *__restrict__ w, int Cout, int Cin, float *__restrict__ uf,
                                  float *__restrict__ ud) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -295,12 +428,12 @@ __global__ void wino_pack_kernel(const float *__restrict__ w, int Cout, int Cin,
             t[3][kx] = gg[2][kx];
         }
         for (int aa = 0; aa < 4; ++aa) {
-            const double u0 = t[aa][0], u1 = 0.5 * (t[aa][0] + t[aa][1] + t[aa][2]),
-                         u2 = 0.5 * (t[aa][0] - t[aa][1] + t[aa][2]), u3 = t[aa][2];
-            const double u[4] = {u0, u1, u2, u3};
+            const double u[4] = {t[aa][0], 0.5 * (t[aa][0] + t[aa][1] + t[aa][2]), 0.5 * (t[aa][0] - t[aa][1] + t[aa][2]),
+                                 t[aa][2]};
             for (int bb = 0; bb < 4; ++bb) {
                 const int xi = aa * 4 + bb;
-                const size_t o = dir == 0 ? ((size_t)xi * Cin + ci) * Cout + co : ((size_t)xi * Cout + co) * Cin + ci;
+                // forward: M = cout, K = cin ; dgrad: M = cin (the output of the transposed conv), K = cout
+                const size_t o = dir == 0 ? upack_index(co, ci, xi, Cin) : upack_index(ci, co, xi, Cout);
                 out[o] = (float)u[bb];
             }
         }
@@ -313,14 +446,15 @@ int launch_wino(WinoArgs a, hipStream_t s) {
     a.tiles_y = st3d::cdiv(a.H, TROWS);
     a.n_ct = a.Cout / BCO;
     const long blocks = (long)a.n_ct * a.tiles_x * a.tiles_y * a.N;
-    if (a.yp) wino_kernel<MODE, 1><<<(unsigned)blocks, NT, 0, s>>>(a);
+    if (a.dbg && MODE == 0 && !a.yp) wino_kernel<0, 0, 1><<<(unsigned)blocks, NT, 0, s>>>(a);
+    else if (a.yp) wino_kernel<MODE, 1><<<(unsigned)blocks, NT, 0, s>>>(a);
     else wino_kernel<MODE, 0><<<(unsigned)blocks, NT, 0, s>>>(a);
     ST3D_LAUNCH_CHECK();
     return ST3D_OK;
 }
 
 bool shape_ok(int Cin, int Cout, int H, int W) {
-    return Cin >= 64 && (Cin % 4) == 0 && (Cout % 64) == 0 && (H % 2) == 0 && (W % 2) == 0;
+    return Cin >= 8 && (Cin % 8) == 0 && (Cout % 64) == 0 && (H % 2) == 0 && (W % 4) == 0;
 }
 
 }  // namespace
@@ -343,7 +477,8 @@ extern "C" int st3d_wino_fwd(const float *x, const float *u_fwd, const float *bi
     ST3D_CHECK_ARG(N > 0 && shape_ok(Cin, Cout, H, W));
     ST3D_CHECK_ARG((size_t)Cin * H * W < (1u << 31) && (size_t)Cout * H * W < (1u << 31));
     ST3D_CHECK_ARG(((uintptr_t)u_fwd & 15) == 0);
-    WinoArgs a{x, nullptr, nullptr, u_fwd, bias, y, y_pooled, pool_idx, N, Cin, Cout, H, W, relu, 0, 0, 0};
+    WinoArgs a{x, nullptr, nullptr, u_fwd, bias, y, y_pooled, pool_idx, N, Cin, Cout, H, W, relu, 0, 0, 0,
+               getenv("ST3D_WINO_STAMP") ? reinterpret_cast<unsigned long long *>(strtoull(getenv("ST3D_WINO_STAMP"), nullptr, 0)) : nullptr};
     return launch_wino<0>(a, st3d::as_stream(stream));
 }
 
@@ -353,7 +488,7 @@ extern "C" int st3d_wino_dgrad(const float *gy, const float *act, const float *u
     ST3D_CHECK_ARG(N > 0 && shape_ok(Cout, Cin, H, W));
     ST3D_CHECK_ARG((size_t)Cin * H * W < (1u << 31) && (size_t)Cout * H * W < (1u << 31));
     ST3D_CHECK_ARG(((uintptr_t)u_dgrad & 15) == 0);
-    WinoArgs a{gy, act, nullptr, u_dgrad, nullptr, gx, nullptr, nullptr, N, Cout, Cin, H, W, 0, 0, 0, 0};
+    WinoArgs a{gy, act, nullptr, u_dgrad, nullptr, gx, nullptr, nullptr, N, Cout, Cin, H, W, 0, 0, 0, 0, nullptr};
     return act ? launch_wino<1>(a, st3d::as_stream(stream)) : launch_wino<0>(a, st3d::as_stream(stream));
 }
 
@@ -364,6 +499,6 @@ extern "C" int st3d_wino_dgrad_unpool(const float *gy_pooled, const uint8_t *poo
     ST3D_CHECK_ARG(N > 0 && shape_ok(Cout, Cin, H, W));
     ST3D_CHECK_ARG((size_t)Cin * H * W < (1u << 31) && (size_t)Cout * H * W < (1u << 31));
     ST3D_CHECK_ARG(((uintptr_t)u_dgrad & 15) == 0);
-    WinoArgs a{gy_pooled, pooled, pool_idx, u_dgrad, nullptr, gx, nullptr, nullptr, N, Cout, Cin, H, W, 0, 0, 0, 0};
+    WinoArgs a{gy_pooled, pooled, pool_idx, u_dgrad, nullptr, gx, nullptr, nullptr, N, Cout, Cin, H, W, 0, 0, 0, 0, nullptr};
     return launch_wino<2>(a, st3d::as_stream(stream));
 }

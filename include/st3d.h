@@ -122,8 +122,8 @@ int st3d_conv3x3_dgrad_unpool(const float *gy_pooled, const uint8_t *pool_idx, c
                               const float *w_dgrad_packed, float *gx, int N, int Cin, int Cout,
                               int H, int W, st3d_stream_t stream);
 /* Winograd F(2x2,3x3) variants of the three conv entry points above (exact-fp32 MFMA products,
- * 2.25x fewer of them); for Cin >= 64, Cin % 4 == 0, Cout % 64 == 0, H and W even -- every VGG
- * layer but conv1_1.  u_fwd = [16][Cin][Cout], u_dgrad = [16][Cout][Cin] (st3d_wino_pack).
+ * 2.25x fewer of them); for Cin % 8 == 0, Cout % 64 == 0, H even, W % 4 == 0 -- every VGG
+ * layer but conv1_1.  u_fwd / u_dgrad = G g G^T in the kernel's MFMA-operand order (st3d_wino_pack).
  * st3d_wino_fwd can fuse the following MaxPool2d(2,2): y_pooled (N,Cout,H/2,W/2) + pool_idx
  * (either NULL = no pooling); y may then be NULL to skip the full-resolution store. */
 int st3d_wino_supported(int Cin, int Cout, int H, int W);
