@@ -246,6 +246,68 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float *__restrict__ 
     if (idx) idx[i] = (uint8_t)bi;
 }
 
+// Input gradient of a conv with <= 4 INPUT channels (conv1_1: 64 -> 3 at full resolution).  With
+// M = 3 the implicit GEMM would waste 29/32 of every MFMA, and the layer is HBM-bound anyway
+// (reads the 64-channel gradient + its ReLU gate: 2 x 64 x H x W x 4 B, writes 3 x H x W x 4 B),
+// so it runs on the vector ALU: one thread per pixel, 3 accumulators, the gated gradient tile
+// [8][10][34] staged in LDS with 16-byte loads, weights read as scalars (wave-uniform).
+// wd is the dgrad pack [tap'][CoutP4][CinP128] of pack_kernel.
+constexpr int SG_KC = 8, SG_TH = 8, SG_PCP = 40;     // LDS row pitch 40: columns x0-4 .. x0+35
+template <int CI>
+__global__ __launch_bounds__(256) void dgrad_small_kernel(const float *__restrict__ gy, const float *__restrict__ act,
+                                                          const float *__restrict__ wd, float *__restrict__ gx, int Cout,
+                                                          int CoutP4, int H, int W, int tiles_x) {
+    __shared__ __attribute__((aligned(16))) float tile[SG_KC][SG_TH + 2][SG_PCP];
+    const int tid = threadIdx.x;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, n = blockIdx.y;
+    const int x0 = tx * 32, y0 = ty * SG_TH;
+    const int px = tid & 31, py = tid >> 5;
+    const size_t HW = (size_t)H * W;
+    const float *gb = gy + (size_t)n * Cout * HW;
+    const float *ab = act ? act + (size_t)n * Cout * HW : nullptr;
+    // staging items: 8 channels x 10 rows x 10 float4 (columns x0-4+4l .. +3); W % 4 == 0 so an item is
+    // entirely inside or outside the image
+    constexpr int ITEMS = SG_KC * (SG_TH + 2) * 10;
+    float acc[CI];
+#pragma unroll
+    for (int i = 0; i < CI; ++i) acc[i] = 0.f;
+    for (int c0 = 0; c0 < Cout; c0 += SG_KC) {
+        __syncthreads();
+        for (int e = tid; e < ITEMS; e += 256) {
+            const int ci = e / 100, rem = e - ci * 100, r = rem / 10, l = rem - r * 10;
+            const int yy = y0 + r - 1, xx = x0 - 4 + 4 * l;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W && c0 + ci < Cout) {
+                const size_t o = (size_t)(c0 + ci) * HW + (size_t)yy * W + xx;
+                v = *reinterpret_cast<const float4 *>(gb + o);
+                if (ab) {
+                    const float4 m = *reinterpret_cast<const float4 *>(ab + o);
+                    v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
+                    v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+                }
+            }
+            *reinterpret_cast<float4 *>(&tile[ci][r][4 * l]) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < SG_KC; ++c) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap - ky * 3;
+                const float v = tile[c][py + ky][px + kx + 3];        // column x0-1+px+kx sits at LDS column +3
+                const float *wr = wd + ((size_t)tap * CoutP4 + (c0 + c)) * 128;   // wave-uniform: scalar loads
+#pragma unroll
+                for (int i = 0; i < CI; ++i) acc[i] += v * wr[i];
+            }
+        }
+    }
+    const int ox = x0 + px, oy = y0 + py;
+    if (ox < W && oy < H) {
+#pragma unroll
+        for (int i = 0; i < CI; ++i) gx[((size_t)n * CI + i) * HW + (size_t)oy * W + ox] = acc[i];
+    }
+}
+
 template <int MODE>
 int launch_conv(const ConvArgs &a0, hipStream_t s) {
     ConvArgs a = a0;
@@ -302,6 +364,13 @@ extern "C" int st3d_conv3x3_dgrad(const float *gy, const float *act, const float
     ST3D_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0);
     ST3D_CHECK_ARG((size_t)Cin * H * W < (1u << 31) && (size_t)Cout * H * W < (1u << 31));
     ST3D_CHECK_ARG(((uintptr_t)w_dgrad_packed & 15) == 0);
+    if (Cin == 3 && (W % 4) == 0 && (Cout % SG_KC) == 0 && ceil_to(Cin, 128) == 128) {     // conv1_1: HBM-bound VALU kernel
+        const int tiles_x = st3d::cdiv(W, 32);
+        dgrad_small_kernel<3><<<dim3(tiles_x * st3d::cdiv(H, SG_TH), N), 256, 0, st3d::as_stream(stream)>>>(
+            gy, act, w_dgrad_packed, gx, Cout, ceil_to(Cout, 4), H, W, tiles_x);
+        ST3D_LAUNCH_CHECK();
+        return ST3D_OK;
+    }
     // the transposed convolution reads Cout channels and writes Cin channels
     ConvArgs a{gy, act, nullptr, w_dgrad_packed, nullptr, gx, N, Cout, Cin, H, W, ceil_to(Cout, 4), ceil_to(Cin, 128), 0, 0};
     return act ? launch_conv<1>(a, st3d::as_stream(stream)) : launch_conv<0>(a, st3d::as_stream(stream));
