@@ -31,7 +31,8 @@ def init_distributed(backend=None):
     rank, world, local = dist_info()
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # ST3D_DIST_BACKEND=gloo: rehearse the N>1 path with several ranks sharing one GPU (RCCL refuses that)
+            backend = os.environ.get("ST3D_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -129,7 +129,7 @@ def main():
             raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libst3d has no CPU fallback")
-    device = torch.device(f"cuda:{local}")
+    device = torch.device(f"cuda:{local % max(torch.cuda.device_count(), 1)}")     # > device_count only in gloo rehearsals
     torch.cuda.set_device(device)
 
     import losses as L
@@ -227,6 +227,15 @@ def main():
         achieved = f_alg_step / (dev_ms / args.steps * 1e-3)
         f_exec_step = F_EXEC_VIEW_512 * s2 * Bv if os.environ.get("ST3D_CONV") != "direct" else f_alg_step
         executed = f_exec_step / (dev_ms / args.steps * 1e-3)
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "r01_c_pmc_traffic.json")
+        if os.path.exists(tpath) and S == 512 and Bv == 8 and not args.no_hoist:
+            with open(tpath) as fh:
+                tj = json.load(fh)
+            traffic = tj["fetch_bytes_raw_per_step"] + tj["write_bytes_per_step"]
+            traffic_src = ("HBM bytes per step (whole step = the priced unit) from committed PMC passes, not measured live: "
+                           "profiles/r01_c_pmc_traffic.json; FETCH_SIZE raw (gfx950 under-reports 16-B/lane streams by up to 2x) "
+                           "+ WRITE_SIZE")
         res = {
             "metric": "style-transfer iters/sec (512x512, 8 views, cow_mesh)",
             "value": round(args.steps * world * (Bv / 8.0) / elapsed, 4),
@@ -241,7 +250,8 @@ def main():
                        "targets_hoisted": not args.no_hoist, "parallelism": "views sharded dp%d, RCCL all-reduce of the texture gradient" % world},
             "final_loss": final_loss,
             "roofline": {"bound": "mfma", "achieved": round(achieved / 1e12, 3), "peak": PEAK_FP32_MFMA / 1e12,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "executed": round(executed / 1e12, 3), "executed_frac": round(executed / PEAK_FP32_MFMA, 4),
                          "kernel": "whole step (per GPU). achieved = ALGORITHMIC flops of the direct convolutions + Grams "
                                    "(%.1f GF/step, SURVEY 8d) over the HIP-event time (%.3f ms/step); it can exceed the fp32 "
