@@ -183,9 +183,16 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const float *__restric
     gram[b * CC + i] = s;
 }
 
-int gram_split(int C, int HW, int *kper) {
-    int ns = (HW + 2047) / 2048;
-    if (C >= 256 && ns < 4 && HW >= 4 * 256) ns = 4;
+// K split: enough workgroups to fill the chip twice over (256 CUs x 2 resident workgroups x 2), but
+// at least 8 K-chunks of work per workgroup and at most 256 slabs.
+int gram_split(int B, int C, int HW, int *kper) {
+    const int nt = (C % 128 == 0) ? C / 128 : (C + 63) / 64;
+    const int pairs = nt * (nt + 1) / 2;
+    int ns = (1024 + pairs * B - 1) / (pairs * B);
+    const int ns_bytes = (HW + 2047) / 2048;            // never more than 2048 pixels per workgroup
+    if (ns < ns_bytes) ns = ns_bytes;
+    const int ns_max = (HW + 8 * KCH - 1) / (8 * KCH);
+    if (ns > ns_max) ns = ns_max;
     if (ns > 256) ns = 256;
     if (ns < 1) ns = 1;
     int kp = (HW + ns - 1) / ns;
@@ -199,7 +206,7 @@ int gram_split(int C, int HW, int *kper) {
 
 extern "C" size_t st3d_gram_workspace_bytes(int B, int C, int HW) {
     int kper;
-    const int ns = gram_split(C, HW, &kper);
+    const int ns = gram_split(B, C, HW, &kper);
     return (size_t)B * ns * C * C * sizeof(float);
 }
 
@@ -211,7 +218,7 @@ extern "C" int st3d_gram_fwd(const float *feat, int B, int C, int HW, void *work
     hipStream_t s = st3d::as_stream(stream);
     GemmArgs g;
     memset(&g, 0, sizeof(g));
-    g.nsplit = gram_split(C, HW, &g.kper);
+    g.nsplit = gram_split(B, C, HW, &g.kper);
     g.A = feat; g.B = feat; g.C = reinterpret_cast<float *>(workspace);
     g.M = C; g.N = C; g.K = HW; g.lda = HW; g.ldb = HW; g.ldc = C;
     g.sA = g.sB = (size_t)C * HW;
