@@ -66,13 +66,22 @@ def load_scene(obj_path, size, resize_texture, device):
     """reference second_approach.py:77-97"""
     verts, faces, aux = st3d_io.load_obj(obj_path)
     if aux.verts_uvs is None or faces.textures_idx is None or not aux.texture_images:
-        raise ValueError(f"{obj_path} has no UVs / texture (the reference crashes on such meshes too, SURVEY.md D3); "
-                         "use st3d.io.synthesize_uvs")
+        # e.g. objects/teapot_mesh/teapot.obj (faces `v//vn`, no mtllib): the reference crashes at
+        # first_approach.py:85-88 (SURVEY.md D3), so there is no behaviour to match.  Per-vertex spherical UVs
+        # and a mid-grey texture with seeded noise are synthesised so BASELINE config 4 can run.
+        print(f"WARNING: {obj_path} has no UVs / texture; synthesising spherical UVs and a grey noise texture")
+        verts_uvs_cpu = st3d_io.synthesize_uvs(verts)
+        faces_uvs_cpu = faces.verts_idx.clone()
+        g = torch.Generator().manual_seed(0)
+        tex_cpu = (0.5 + 0.1 * torch.randn((size, size, 3), generator=g)).clamp(0, 1)
+    else:
+        verts_uvs_cpu, faces_uvs_cpu = aux.verts_uvs, faces.textures_idx
+        tex_cpu = list(aux.texture_images.values())[0]
     verts = verts.to(device)
-    verts_uvs = aux.verts_uvs[None, ...].to(device)  # (1, V, 2)
-    faces_uvs = faces.textures_idx[None, ...].to(device)  # (1, F, 3)
+    verts_uvs = verts_uvs_cpu[None, ...].to(device)  # (1, V, 2)
+    faces_uvs = faces_uvs_cpu[None, ...].to(device)  # (1, F, 3)
     faces_idx = faces.verts_idx.to(device)
-    texture_image = list(aux.texture_images.values())[0][None, ...].to(device)  # (1, H, W, 3)
+    texture_image = tex_cpu[None, ...].to(device)  # (1, H, W, 3)
     if resize_texture:
         texture_image = F.interpolate(texture_image.permute(0, 3, 1, 2), size=size, mode='bilinear',
                                       align_corners=False).permute(0, 2, 3, 1).contiguous()

@@ -90,8 +90,9 @@ def test_gram_matrix_autograd(mods):
 
 @pytest.mark.parametrize("fixture,B,S", [("g3_perceptual.npz", 2, 64), ("g3b_perceptual_96.npz", 1, 96)])
 def test_compute_perceptual_loss_matches_reference_golden(mods, vgg, golden_dir, fixture, B, S):
-    """loss within 2e-4 relative, d loss/d current within 1e-3 relative L2 of the reference's
-    losses.compute_perceptual_loss + autograd (fp32, different summation order)."""
+    """loss within 2e-5 relative, d loss/d current within 1e-4 relative L2 of the reference's
+    losses.compute_perceptual_loss + autograd (fp32, different summation order; measured 4e-7 / 2e-6,
+    tools/parity_margins.py)."""
     _, L, _, dev = mods
     d = np.load(os.path.join(golden_dir, fixture))
     cur = torch.from_numpy(d["cur"]).to(dev).requires_grad_(True)
@@ -100,9 +101,9 @@ def test_compute_perceptual_loss_matches_reference_golden(mods, vgg, golden_dir,
         kw = {"style_weight": float(d["style_weight"]), "content_weight": float(d["content_weight"])}
     loss = L.compute_perceptual_loss(cur, torch.from_numpy(d["con"]).to(dev), torch.from_numpy(d["sty"]).to(dev), vgg, **kw)
     loss.backward()
-    assert abs(loss.item() - float(d["loss"])) <= 2e-4 * float(d["loss"])
+    assert abs(loss.item() - float(d["loss"])) <= 2e-5 * float(d["loss"])
     gref = torch.from_numpy(d["grad"])
-    assert float((cur.grad.cpu() - gref).norm() / gref.norm()) <= 1e-3
+    assert float((cur.grad.cpu() - gref).norm() / gref.norm()) <= 1e-4
     # the 'texture' branch of compute_second_approach_loss is the same number (losses.py:103-104)
     l2 = L.compute_second_approach_loss(cur.detach(), torch.from_numpy(d["con"]).to(dev), torch.from_numpy(d["sty"]).to(dev),
                                         vgg, kw.get("style_weight", 1e6), kw.get("content_weight", 1), None, None, None, {},
@@ -128,8 +129,8 @@ def test_first_approach_loss_matches_reference_golden(mods, golden_dir):
 
 
 def test_style_transfer_matches_reference_trajectory(mods, vgg, golden_dir):
-    """Six steps of the reference's style_transfer() (golden G4): final pixels within 5e-4 abs
-    (Adam's m/sqrt(v) normalisation amplifies tiny gradient differences in the first steps)."""
+    """Six steps of the reference's style_transfer() (golden G4): final pixels within 1e-4 abs
+    (Adam's m/sqrt(v) normalisation amplifies tiny gradient differences in the first steps; measured 9e-6)."""
     ST, _, _, dev = mods
     d = np.load(os.path.join(golden_dir, "g4_style_transfer.npz"))
     res = ST.style_transfer(torch.from_numpy(d["init"]).to(dev), torch.from_numpy(d["con"]).to(dev),
@@ -137,7 +138,7 @@ def test_style_transfer_matches_reference_trajectory(mods, vgg, golden_dir):
                             content_weight=1, lr=float(d["lr"]))
     assert res.requires_grad and res.is_leaf
     err = (res.detach().cpu() - torch.from_numpy(d["result"])).abs()
-    assert float(err.max()) <= 5e-4, float(err.max())
+    assert float(err.max()) <= 1e-4, float(err.max())
     moved = (torch.from_numpy(d["result"]) - torch.from_numpy(d["init"])).abs().mean()
     assert float(err.mean()) <= 0.01 * float(moved)
 
@@ -363,3 +364,21 @@ def test_second_approach_cli_both_target(mods, cow, golden_dir, tmp_path):
     log = open(os.path.join(outp, "log.txt")).read().splitlines()
     assert len(log) == 4 and all(np.isfinite(float(line.split("Loss ")[1])) for line in log[1:])
     assert os.path.exists(os.path.join(outp, "final.obj"))
+
+
+def test_mesh_without_uvs_gets_synthesised_ones(mods, golden_dir, tmp_path):
+    """teapot-style OBJ (`v//vn` faces, no mtllib: SURVEY.md D3, BASELINE config 4): the reference crashes; the
+    drop-in synthesises spherical UVs + a texture and runs."""
+    import second_approach as SA
+    from PIL import Image
+    # octahedron
+    (tmp_path / "o.obj").write_text("v 1 0 0\nv -1 0 0\nv 0 1 0\nv 0 -1 0\nv 0 0 1\nv 0 0 -1\nvn 0 0 1\n"
+                                    "f 1//1 3//1 5//1\nf 3//1 2//1 5//1\nf 2//1 4//1 5//1\nf 4//1 1//1 5//1\n"
+                                    "f 3//1 1//1 6//1\nf 2//1 3//1 6//1\nf 4//1 2//1 6//1\nf 1//1 4//1 6//1\n")
+    sty = np.load(os.path.join(golden_dir, "assets_style1_512.npz"))["rgb_u8"]
+    Image.fromarray(sty).save(tmp_path / "style.png")
+    outp = str(tmp_path / "out_t")
+    SA.main(["--obj_path", str(tmp_path / "o.obj"), "--style_path", str(tmp_path / "style.png"), "--size", "64", "--n_views", "2",
+             "--batch_size", "2", "--epochs", "2", "--output_path", outp, "--seed", "0", "--save_every", "0"])
+    log = open(os.path.join(outp, "log.txt")).read().splitlines()
+    assert len(log) == 3 and all(np.isfinite(float(line.split("Loss ")[1])) for line in log[1:])
