@@ -26,6 +26,7 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-
 SOURCES = {
     "raster.hip": ["-ffp-contract=off"],
     "shade.hip": ["-ffp-contract=off"],
+    "soft.hip": ["-ffp-contract=off"],
     "conv.hip": [],
     "wino.hip": ["-fno-slp-vectorize"],   # SLP-packed f32 (v_pk_*) needs register shuffles that cost matrix-pipe time
     "gram.hip": [],

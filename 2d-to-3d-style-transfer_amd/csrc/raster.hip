@@ -196,6 +196,17 @@ extern "C" int st3d_project_verts(const float *verts, int V, const float *R, con
 
 extern "C" size_t st3d_raster_workspace_bytes(int B, int F) { return (size_t)B * (size_t)F * 3 * sizeof(float4); }
 
+extern "C" int st3d_face_setup(const float *verts_ndc, const int32_t *faces, int B, int V, int F, void *face_records,
+                               size_t records_bytes, st3d_stream_t stream) {
+    ST3D_CHECK_ARG(verts_ndc && faces && face_records);
+    ST3D_CHECK_ARG(B > 0 && V > 0 && F > 0 && records_bytes >= st3d_raster_workspace_bytes(B, F));
+    ST3D_CHECK_ARG(((uintptr_t)face_records & 15) == 0);
+    face_setup_kernel<<<st3d::cdiv((long)B * F, 256), 256, 0, st3d::as_stream(stream)>>>(verts_ndc, faces, B, V, F,
+                                                                                       reinterpret_cast<float4 *>(face_records));
+    ST3D_LAUNCH_CHECK();
+    return ST3D_OK;
+}
+
 extern "C" int st3d_raster_fwd(const float *verts_ndc, const int32_t *faces, int B, int V, int F, int S, void *workspace,
                                size_t workspace_bytes, int32_t *pix_to_face, float *zbuf, float *bary, float *dists,
                                st3d_stream_t stream) {

@@ -1,0 +1,473 @@
+// soft.hip -- the GENERAL soft renderer: K = faces_per_pixel nearest faces per pixel, blur_radius
+// >= 0 (faces contribute up to sqrt(blur) outside their edges), barycentric clipping, and
+// softmax_rgb_blend over the K layers (sigma, gamma, background), forward and backward
+// (texture, barycentric, depth and edge-distance gradients -> vertices).
+// The reference fixes K = 1 / blur = 0 (first_approach.py:107, second_approach.py:101) and runs on
+// the specialised kernels of raster.hip / shade.hip; this file is the general form named by the
+// north star ("soft rasteriser ... soft-aggregation z-blend").  Same structure:
+// one 256-thread workgroup per 16x16 tile, order-preserving ballot compaction of the faces whose
+// padded bbox touches the tile into an LDS list, every lane (= pixel) walks the list keeping its K
+// nearest candidates in registers (insertion into a depth-sorted list, K is a template parameter
+// so the list never leaves the VGPRs).  HBM-bound: S*S*K*24 B of fragments per view.
+// Built with -ffp-contract=off: same operation order as oracle/raster_ref.c:ref_rasterize_k.
+#include "common.h"
+
+namespace {
+
+constexpr float kEps = 1e-8f;
+constexpr int TILE = 16;
+constexpr int LIST_CAP = 512;
+constexpr float kBlendEps = 1e-10f, kZnear = 1.0f, kZfar = 100.0f;
+
+__device__ __forceinline__ float pix_to_ndc(int i, int S) { return -1.0f + (2.0f * (float)i + 1.0f) / (float)S; }
+__device__ __forceinline__ float edge_fn(float px, float py, float ax, float ay, float bx, float by) {
+    return (px - ax) * (by - ay) - (py - ay) * (bx - ax);
+}
+__device__ __forceinline__ float pld2(float px, float py, float ax, float ay, float bx, float by) {
+    const float bax = bx - ax, bay = by - ay;
+    const float l2 = bax * bax + bay * bay;
+    if (l2 <= kEps) {
+        const float dx = px - bx, dy = py - by;
+        return dx * dx + dy * dy;
+    }
+    float t = (bax * (px - ax) + bay * (py - ay)) / l2;
+    t = t < 0.f ? 0.f : (t > 1.f ? 1.f : t);
+    const float qx = ax + t * bax, qy = ay + t * bay;
+    const float dx = qx - px, dy = qy - py;
+    return dx * dx + dy * dy;
+}
+
+// face records as in raster.hip: [x0 y0 z0 x1][y1 z1 x2 y2][z2 valid 0 0]
+template <int K>
+__global__ __launch_bounds__(256) void raster_k_kernel(const float4 *__restrict__ rec, int F, int S, float blur, int clip,
+                                                       int32_t *__restrict__ pix_to_face, float *__restrict__ zbuf,
+                                                       float *__restrict__ bary, float *__restrict__ dists) {
+    __shared__ float s_face[LIST_CAP][9];
+    __shared__ int s_fidx[LIST_CAP];
+    __shared__ int s_wcnt[4];
+
+    const int b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int px = blockIdx.x * TILE + (tid & (TILE - 1));
+    const int py = blockIdx.y * TILE + (tid >> 4);
+    const bool in_img = px < S && py < S;
+    const float xf = pix_to_ndc(S - 1 - px, S), yf = pix_to_ndc(S - 1 - py, S);
+    const float pad = sqrtf(blur);
+    const int px_hi = min(blockIdx.x * TILE + TILE - 1, S - 1), py_hi = min(blockIdx.y * TILE + TILE - 1, S - 1);
+    const float tx_max = pix_to_ndc(S - 1 - blockIdx.x * TILE, S), tx_min = pix_to_ndc(S - 1 - px_hi, S);
+    const float ty_max = pix_to_ndc(S - 1 - blockIdx.y * TILE, S), ty_min = pix_to_ndc(S - 1 - py_hi, S);
+    const float4 *rb = rec + (size_t)b * F * 3;
+
+    int qf[K]; float qz[K], qd[K], qb0[K], qb1[K], qb2[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { qf[k] = -1; qz[k] = 3.0e38f; qd[k] = -1.f; qb0[k] = qb1[k] = qb2[k] = -1.f; }
+
+    int count = 0;
+    for (int base = 0; base < F; base += 256) {
+        const int f = base + tid;
+        bool hit = false;
+        float4 r0, r1, r2;
+        if (f < F) {
+            r0 = rb[3 * (size_t)f]; r1 = rb[3 * (size_t)f + 1]; r2 = rb[3 * (size_t)f + 2];
+            const float xmin = fminf(r0.x, fminf(r0.w, r1.z)) - pad, xmax = fmaxf(r0.x, fmaxf(r0.w, r1.z)) + pad;
+            const float ymin = fminf(r0.y, fminf(r1.x, r1.w)) - pad, ymax = fmaxf(r0.y, fmaxf(r1.x, r1.w)) + pad;
+            hit = (r2.y != 0.f) && !(tx_min > xmax || tx_max < xmin || ty_min > ymax || ty_max < ymin);
+        }
+        const unsigned long long m = __ballot(hit);
+        if (lane == 0) s_wcnt[wave] = __popcll(m);
+        __syncthreads();
+        int off = count;
+        for (int w = 0; w < wave; ++w) off += s_wcnt[w];
+        const int total = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+        if (hit) {
+            const int slot = off + __popcll(m & ((1ull << lane) - 1ull));
+            s_fidx[slot] = f;
+            s_face[slot][0] = r0.x; s_face[slot][1] = r0.y; s_face[slot][2] = r0.z;
+            s_face[slot][3] = r0.w; s_face[slot][4] = r1.x; s_face[slot][5] = r1.y;
+            s_face[slot][6] = r1.z; s_face[slot][7] = r1.w; s_face[slot][8] = r2.x;
+        }
+        count += total;
+        __syncthreads();
+        if (count > LIST_CAP - 256 || base + 256 >= F) {
+            for (int i = 0; i < count; ++i) {
+                const float x0 = s_face[i][0], y0 = s_face[i][1], z0 = s_face[i][2];
+                const float x1 = s_face[i][3], y1 = s_face[i][4], z1 = s_face[i][5];
+                const float x2 = s_face[i][6], y2 = s_face[i][7], z2 = s_face[i][8];
+                const float xmin = fminf(x0, fminf(x1, x2)) - pad, xmax = fmaxf(x0, fmaxf(x1, x2)) + pad;
+                const float ymin = fminf(y0, fminf(y1, y2)) - pad, ymax = fmaxf(y0, fmaxf(y1, y2)) + pad;
+                if (xf > xmax || xf < xmin || yf > ymax || yf < ymin) continue;
+                const float area = edge_fn(x2, y2, x0, y0, x1, y1) + kEps;
+                const float w0 = edge_fn(xf, yf, x1, y1, x2, y2) / area;
+                const float w1 = edge_fn(xf, yf, x2, y2, x0, y0) / area;
+                const float w2 = edge_fn(xf, yf, x0, y0, x1, y1) / area;
+                const float t0 = w0 * z1 * z2, t1 = z0 * w1 * z2, t2 = z0 * z1 * w2;
+                const float den = fmaxf(t0 + t1 + t2, kEps);
+                const float b0 = t0 / den, b1 = t1 / den, b2 = t2 / den;
+                float c0 = b0, c1 = b1, c2 = b2;
+                if (clip) {
+                    c0 = fminf(fmaxf(b0, 0.f), 1.f); c1 = fminf(fmaxf(b1, 0.f), 1.f); c2 = fminf(fmaxf(b2, 0.f), 1.f);
+                    const float s = fmaxf(c0 + c1 + c2, kEps);
+                    c0 /= s; c1 /= s; c2 /= s;
+                }
+                const float pz = c0 * z0 + c1 * z1 + c2 * z2;
+                if (pz < 0.f) continue;
+                const bool inside = (b0 > 0.f) && (b1 > 0.f) && (b2 > 0.f);
+                const float d = fminf(pld2(xf, yf, x0, y0, x1, y1), fminf(pld2(xf, yf, x1, y1, x2, y2), pld2(xf, yf, x2, y2, x0, y0)));
+                if (!inside && d >= blur) continue;
+                if (!(pz < qz[K - 1])) continue;          // not among the K nearest (ties keep the earlier face)
+                // sorted insertion, fully unrolled: the list stays in registers
+                // (once the new fragment is placed every later slot shifts unconditionally, so equal-z entries
+                // already in the list keep their order)
+                int cf = s_fidx[i]; float cz = pz, cd = inside ? -d : d, e0 = c0, e1 = c1, e2 = c2;
+                bool placed = false;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    if (placed || cz < qz[k]) {
+                        placed = true;
+                        const int tf = qf[k]; const float tz = qz[k], td = qd[k], u0 = qb0[k], u1 = qb1[k], u2 = qb2[k];
+                        qf[k] = cf; qz[k] = cz; qd[k] = cd; qb0[k] = e0; qb1[k] = e1; qb2[k] = e2;
+                        cf = tf; cz = tz; cd = td; e0 = u0; e1 = u1; e2 = u2;
+                    }
+                }
+            }
+            count = 0;
+            __syncthreads();
+        }
+    }
+    if (!in_img) return;
+    const size_t p = (((size_t)b * S + py) * S + px) * K;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const bool ok = qf[k] >= 0;
+        pix_to_face[p + k] = qf[k];
+        zbuf[p + k] = ok ? qz[k] : -1.f;
+        dists[p + k] = qd[k];
+        bary[3 * (p + k)] = qb0[k]; bary[3 * (p + k) + 1] = qb1[k]; bary[3 * (p + k) + 2] = qb2[k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------ shading
+struct Footprint { int x0, x1, r0, r1; float wx0, wx1, wy0, wy1; bool vx0, vx1, vy0, vy1, cx, cy; };
+__device__ __forceinline__ Footprint uv_footprint(float u, float v, int T) {
+    Footprint o;
+    const float gx = u * 2.0f - 1.0f, gy = v * 2.0f - 1.0f;
+    float ix = ((gx + 1.0f) / 2.0f) * (float)(T - 1);
+    float iy = ((gy + 1.0f) / 2.0f) * (float)(T - 1);
+    o.cx = false; o.cy = false;
+    if (!(ix >= 0.f)) { ix = 0.f; o.cx = true; } else if (ix > (float)(T - 1)) { ix = (float)(T - 1); o.cx = true; }
+    if (!(iy >= 0.f)) { iy = 0.f; o.cy = true; } else if (iy > (float)(T - 1)) { iy = (float)(T - 1); o.cy = true; }
+    const float fx = floorf(ix), fy = floorf(iy);
+    o.x0 = (int)fx; o.x1 = o.x0 + 1;
+    const int yf0 = (int)fy, yf1 = yf0 + 1;
+    o.wx1 = ix - fx; o.wx0 = 1.0f - o.wx1;
+    o.wy1 = iy - fy; o.wy0 = 1.0f - o.wy1;
+    o.vx0 = o.x0 >= 0 && o.x0 < T; o.vx1 = o.x1 >= 0 && o.x1 < T;
+    o.vy0 = yf0 >= 0 && yf0 < T;   o.vy1 = yf1 >= 0 && yf1 < T;
+    o.r0 = (T - 1) - yf0; o.r1 = (T - 1) - yf1;
+    return o;
+}
+
+struct SoftArgs {
+    const int32_t *p2f; const float *bary, *zbuf, *dists, *uvs; const int32_t *fuv; const float *tex;
+    int B, S, T, K; float sigma, gamma, bg0, bg1, bg2;
+};
+
+// one thread per pixel, loop over the K layers twice (z_max first).  MODE 0: forward (rgb, alpha);
+// MODE 1: backward (texture atomics + per-layer d/d bary, d/d zbuf, d/d dists)
+template <int MODE>
+__global__ __launch_bounds__(256) void soft_shade_kernel(const SoftArgs a, float *__restrict__ rgb, float *__restrict__ alpha_out,
+                                                         const float *__restrict__ grad_rgb, float *__restrict__ gtex,
+                                                         float *__restrict__ gbary, float *__restrict__ gz, float *__restrict__ gd) {
+    const size_t HW = (size_t)a.S * a.S;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)a.B * HW) return;
+    const size_t b = i / HW, p = i - b * HW;
+    const int K = a.K, T = a.T;
+    const float zr = 1.0f / (kZfar - kZnear);
+    // pass 1: z_max (argmax = first maximum, as torch.max) and alpha
+    float z_max = 0.f; int kmax = -1; float keep = 1.f;
+    for (int k = 0; k < K; ++k) {
+        const int f = a.p2f[i * K + k];
+        if (f < 0) continue;
+        const float z_inv = (kZfar - a.zbuf[i * K + k]) * zr;
+        if (kmax < 0 || z_inv > z_max) { if (kmax < 0 || z_inv > z_max) { z_max = z_inv; kmax = k; } }
+        const float prob = 1.0f / (1.0f + expf(a.dists[i * K + k] / a.sigma));
+        keep *= (1.0f - prob);
+    }
+    if (kmax < 0) z_max = 0.f;                     // all masked: z_inv * mask = 0
+    const bool zclamped = !(z_max > kBlendEps);
+    if (zclamped) z_max = kBlendEps;
+    const float dexp = expf((kBlendEps - z_max) / a.gamma);
+    const bool dclamped = !(dexp > kBlendEps);
+    const float delta = dclamped ? kBlendEps : dexp;
+    // pass 2: weights and colours
+    float wsum = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const int f = a.p2f[i * K + k];
+        if (f < 0) continue;
+        const float prob = 1.0f / (1.0f + expf(a.dists[i * K + k] / a.sigma));
+        const float z_inv = (kZfar - a.zbuf[i * K + k]) * zr;
+        const float w = prob * expf((z_inv - z_max) / a.gamma);
+        const float b0 = a.bary[3 * (i * K + k)], b1 = a.bary[3 * (i * K + k) + 1], b2 = a.bary[3 * (i * K + k) + 2];
+        const int u0 = a.fuv[3 * f], u1 = a.fuv[3 * f + 1], u2 = a.fuv[3 * f + 2];
+        const float u = b0 * a.uvs[2 * u0] + b1 * a.uvs[2 * u1] + b2 * a.uvs[2 * u2];
+        const float v = b0 * a.uvs[2 * u0 + 1] + b1 * a.uvs[2 * u1 + 1] + b2 * a.uvs[2 * u2 + 1];
+        const Footprint q = uv_footprint(u, v, T);
+        const float w00 = q.wx0 * q.wy0, w01 = q.wx1 * q.wy0, w10 = q.wx0 * q.wy1, w11 = q.wx1 * q.wy1;
+        const float *t00 = a.tex + ((size_t)q.r0 * T + q.x0) * 3, *t01 = a.tex + ((size_t)q.r0 * T + q.x1) * 3;
+        const float *t10 = a.tex + ((size_t)q.r1 * T + q.x0) * 3, *t11 = a.tex + ((size_t)q.r1 * T + q.x1) * 3;
+        float t[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float s = 0.f;
+            if (q.vy0 && q.vx0) s += t00[c] * w00;
+            if (q.vy0 && q.vx1) s += t01[c] * w01;
+            if (q.vy1 && q.vx0) s += t10[c] * w10;
+            if (q.vy1 && q.vx1) s += t11[c] * w11;
+            t[c] = s;
+        }
+        wsum += w; c0 += w * t[0]; c1 += w * t[1]; c2 += w * t[2];
+    }
+    const float denom = wsum + delta;
+    const float r0 = (c0 + delta * a.bg0) / denom, r1 = (c1 + delta * a.bg1) / denom, r2 = (c2 + delta * a.bg2) / denom;
+    if (MODE == 0) {
+        float *o = rgb + b * 3 * HW + p;
+        o[0] = r0; o[HW] = r1; o[2 * HW] = r2;
+        alpha_out[i] = 1.0f - keep;
+        return;
+    }
+    // ---- backward
+    const float *g = grad_rgb + b * 3 * HW + p;
+    const float g0 = g[0], g1 = g[HW], g2 = g[2 * HW];
+    const float ddelta = (g0 * (a.bg0 - r0) + g1 * (a.bg1 - r1) + g2 * (a.bg2 - r2)) / denom;
+    float dzmax = dclamped ? 0.f : ddelta * (-delta / a.gamma);
+    // pass 3a: d w_k -> d z_max contributions
+    for (int k = 0; k < K; ++k) {
+        const int f = a.p2f[i * K + k];
+        if (gbary) { gbary[3 * (i * K + k)] = 0.f; gbary[3 * (i * K + k) + 1] = 0.f; gbary[3 * (i * K + k) + 2] = 0.f; }
+        if (gz) gz[i * K + k] = 0.f;
+        if (gd) gd[i * K + k] = 0.f;
+        if (f < 0) continue;
+    }
+    // pass 3b: per-layer gradients (recompute the layer, then scatter)
+    float dz_acc = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const int f = a.p2f[i * K + k];
+        if (f < 0) continue;
+        const float prob = 1.0f / (1.0f + expf(a.dists[i * K + k] / a.sigma));
+        const float z_inv = (kZfar - a.zbuf[i * K + k]) * zr;
+        const float e = expf((z_inv - z_max) / a.gamma);
+        const float w = prob * e;
+        const float b0 = a.bary[3 * (i * K + k)], b1 = a.bary[3 * (i * K + k) + 1], b2 = a.bary[3 * (i * K + k) + 2];
+        const int u0 = a.fuv[3 * f], u1 = a.fuv[3 * f + 1], u2 = a.fuv[3 * f + 2];
+        const float u = b0 * a.uvs[2 * u0] + b1 * a.uvs[2 * u1] + b2 * a.uvs[2 * u2];
+        const float v = b0 * a.uvs[2 * u0 + 1] + b1 * a.uvs[2 * u1 + 1] + b2 * a.uvs[2 * u2 + 1];
+        const Footprint q = uv_footprint(u, v, T);
+        const float w00 = q.wx0 * q.wy0, w01 = q.wx1 * q.wy0, w10 = q.wx0 * q.wy1, w11 = q.wx1 * q.wy1;
+        const size_t o00 = ((size_t)q.r0 * T + q.x0) * 3, o01 = ((size_t)q.r0 * T + q.x1) * 3;
+        const size_t o10 = ((size_t)q.r1 * T + q.x0) * 3, o11 = ((size_t)q.r1 * T + q.x1) * 3;
+        const float kw = w / denom;           // d rgb / d colour_k
+        const float gc[3] = {g0, g1, g2};
+        const float rr[3] = {r0, r1, r2};
+        float gix = 0.f, giy = 0.f, dw = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float t00 = 0.f, t01 = 0.f, t10 = 0.f, t11 = 0.f;
+            const float gck = gc[c] * kw;
+            if (q.vy0 && q.vx0) { t00 = a.tex[o00 + c]; if (gtex) atomicAdd(gtex + o00 + c, gck * w00); }
+            if (q.vy0 && q.vx1) { t01 = a.tex[o01 + c]; if (gtex) atomicAdd(gtex + o01 + c, gck * w01); }
+            if (q.vy1 && q.vx0) { t10 = a.tex[o10 + c]; if (gtex) atomicAdd(gtex + o10 + c, gck * w10); }
+            if (q.vy1 && q.vx1) { t11 = a.tex[o11 + c]; if (gtex) atomicAdd(gtex + o11 + c, gck * w11); }
+            const float tc = t00 * w00 + t01 * w01 + t10 * w10 + t11 * w11;
+            dw += gc[c] * (tc - rr[c]) / denom;
+            gix += gck * ((t01 - t00) * q.wy0 + (t11 - t10) * q.wy1);
+            giy += gck * ((t10 - t00) * q.wx0 + (t11 - t01) * q.wx1);
+        }
+        if (gbary) {
+            const float gu = q.cx ? 0.f : gix * (float)(T - 1), gv = q.cy ? 0.f : giy * (float)(T - 1);
+            gbary[3 * (i * K + k)] = gu * a.uvs[2 * u0] + gv * a.uvs[2 * u0 + 1];
+            gbary[3 * (i * K + k) + 1] = gu * a.uvs[2 * u1] + gv * a.uvs[2 * u1 + 1];
+            gbary[3 * (i * K + k) + 2] = gu * a.uvs[2 * u2] + gv * a.uvs[2 * u2 + 1];
+        }
+        // w = prob * exp((z_inv - z_max)/gamma)
+        const float dprob = dw * e;
+        const float dzinv = dw * w / a.gamma;
+        dzmax -= dzinv;
+        if (gd) gd[i * K + k] = dprob * prob * (1.0f - prob) * (-1.0f / a.sigma);
+        if (gz) gz[i * K + k] = -dzinv * zr;          // z_inv = (zfar - z)/(zfar - znear)
+        (void)dz_acc;
+    }
+    // z_max = max_k z_inv_k (clamped): its gradient goes to the arg-max layer
+    if (gz && kmax >= 0 && !zclamped) gz[i * K + kmax] += -dzmax * zr;
+}
+
+// ------------------------------------------------------------------------------------------ raster backward
+// d loss / d (clipped barycentrics, depth, signed distance) per (pixel, layer) -> projected vertices
+__global__ __launch_bounds__(256) void raster_k_bwd_kernel(const float *__restrict__ gbary, const float *__restrict__ gzb,
+                                                           const float *__restrict__ gdist, const int32_t *__restrict__ p2f,
+                                                           const float *__restrict__ ndc, const int32_t *__restrict__ faces,
+                                                           int B, int V, int S, int K, int clip, float *__restrict__ gndc) {
+    const size_t HW = (size_t)S * S;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * HW * K) return;
+    const int f = p2f[i];
+    if (f < 0) return;
+    const size_t pix = i / K;
+    const size_t b = pix / HW, p = pix - b * HW;
+    const int yi = (int)(p / S), xi = (int)(p - (size_t)yi * S);
+    const float px = pix_to_ndc(S - 1 - xi, S), py = pix_to_ndc(S - 1 - yi, S);
+    const float *vb = ndc + b * (size_t)V * 3;
+    const int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
+    const float x0 = vb[3 * i0], y0 = vb[3 * i0 + 1], z0 = vb[3 * i0 + 2];
+    const float x1 = vb[3 * i1], y1 = vb[3 * i1 + 1], z1 = vb[3 * i1 + 2];
+    const float x2 = vb[3 * i2], y2 = vb[3 * i2 + 1], z2 = vb[3 * i2 + 2];
+    const float A = edge_fn(x2, y2, x0, y0, x1, y1) + kEps;
+    const float w0 = edge_fn(px, py, x1, y1, x2, y2) / A;
+    const float w1 = edge_fn(px, py, x2, y2, x0, y0) / A;
+    const float w2 = edge_fn(px, py, x0, y0, x1, y1) / A;
+    const float t0 = w0 * z1 * z2, t1 = z0 * w1 * z2, t2 = z0 * z1 * w2;
+    const float den = t0 + t1 + t2;
+    float gx0 = 0.f, gy0 = 0.f, gx1 = 0.f, gy1 = 0.f, gx2 = 0.f, gy2 = 0.f, dz0 = 0.f, dz1 = 0.f, dz2 = 0.f;
+    const float b0 = t0 / fmaxf(den, kEps), b1 = t1 / fmaxf(den, kEps), b2 = t2 / fmaxf(den, kEps);
+    // ---- clipped barycentrics + depth
+    float c0 = b0, c1 = b1, c2 = b2, s = 1.f;
+    if (clip) {
+        c0 = fminf(fmaxf(b0, 0.f), 1.f); c1 = fminf(fmaxf(b1, 0.f), 1.f); c2 = fminf(fmaxf(b2, 0.f), 1.f);
+        s = fmaxf(c0 + c1 + c2, kEps);
+        c0 /= s; c1 /= s; c2 /= s;
+    }
+    const float gzk = gzb ? gzb[i] : 0.f;
+    float dc0 = (gbary ? gbary[3 * i] : 0.f) + gzk * z0;
+    float dc1 = (gbary ? gbary[3 * i + 1] : 0.f) + gzk * z1;
+    float dc2 = (gbary ? gbary[3 * i + 2] : 0.f) + gzk * z2;
+    dz0 += gzk * c0; dz1 += gzk * c1; dz2 += gzk * c2;
+    float db0 = dc0, db1 = dc1, db2 = dc2;
+    if (clip) {
+        const float dot = dc0 * c0 + dc1 * c1 + dc2 * c2;
+        const bool live = (fminf(fmaxf(b0, 0.f), 1.f) + fminf(fmaxf(b1, 0.f), 1.f) + fminf(fmaxf(b2, 0.f), 1.f)) > kEps;
+        const float e0 = live ? (dc0 - dot) / s : 0.f, e1 = live ? (dc1 - dot) / s : 0.f, e2 = live ? (dc2 - dot) / s : 0.f;
+        db0 = (b0 > 0.f && b0 < 1.f) ? e0 : 0.f;
+        db1 = (b1 > 0.f && b1 < 1.f) ? e1 : 0.f;
+        db2 = (b2 > 0.f && b2 < 1.f) ? e2 : 0.f;
+    }
+    if (den > kEps) {
+        const float gs = db0 * b0 + db1 * b1 + db2 * b2;
+        const float dt0 = (db0 - gs) / den, dt1 = (db1 - gs) / den, dt2 = (db2 - gs) / den;
+        const float dw0 = dt0 * z1 * z2, dw1 = dt1 * z0 * z2, dw2 = dt2 * z0 * z1;
+        dz0 += dt1 * w1 * z2 + dt2 * z1 * w2;
+        dz1 += dt0 * w0 * z2 + dt2 * z0 * w2;
+        dz2 += dt0 * w0 * z1 + dt1 * z0 * w1;
+        const float de0 = dw0 / A, de1 = dw1 / A, de2 = dw2 / A;
+        const float dA = -(dw0 * w0 + dw1 * w1 + dw2 * w2) / A;
+        gx0 += de1 * -(py - y2) + de2 * (py - y1) + dA * (y2 - y1);
+        gy0 += de1 * (px - x2) + de2 * (x1 - px) + dA * (x1 - x2);
+        gx1 += de0 * (py - y2) + de2 * -(py - y0) + dA * -(y2 - y0);
+        gy1 += de0 * (x2 - px) + de2 * (px - x0) + dA * (x2 - x0);
+        gx2 += de0 * -(py - y1) + de1 * (py - y0) + dA * (y1 - y0);
+        gy2 += de0 * (px - x1) + de1 * (x0 - px) + dA * -(x1 - x0);
+    }
+    // ---- signed squared distance to the nearest edge (first minimum), projection parameter constant
+    if (gdist) {
+        const bool inside = (b0 > 0.f) && (b1 > 0.f) && (b2 > 0.f);
+        const float gdd = inside ? -gdist[i] : gdist[i];
+        const float d01 = pld2(px, py, x0, y0, x1, y1), d12 = pld2(px, py, x1, y1, x2, y2), d20 = pld2(px, py, x2, y2, x0, y0);
+        int e = 0; float dm = d01;
+        if (d12 < dm) { dm = d12; e = 1; }
+        if (d20 < dm) { dm = d20; e = 2; }
+        const float ax = e == 0 ? x0 : (e == 1 ? x1 : x2), ay = e == 0 ? y0 : (e == 1 ? y1 : y2);
+        const float bx = e == 0 ? x1 : (e == 1 ? x2 : x0), by = e == 0 ? y1 : (e == 1 ? y2 : y0);
+        const float bax = bx - ax, bay = by - ay, l2 = bax * bax + bay * bay;
+        float gax, gay, gbx, gby;
+        if (l2 <= kEps) {
+            gax = 0.f; gay = 0.f; gbx = gdd * 2.f * (bx - px); gby = gdd * 2.f * (by - py);
+        } else {
+            float t = (bax * (px - ax) + bay * (py - ay)) / l2;
+            t = t < 0.f ? 0.f : (t > 1.f ? 1.f : t);
+            const float qx = ax + t * bax - px, qy = ay + t * bay - py;
+            gax = gdd * (1.f - t) * 2.f * qx; gay = gdd * (1.f - t) * 2.f * qy;
+            gbx = gdd * t * 2.f * qx; gby = gdd * t * 2.f * qy;
+        }
+        if (e == 0) { gx0 += gax; gy0 += gay; gx1 += gbx; gy1 += gby; }
+        else if (e == 1) { gx1 += gax; gy1 += gay; gx2 += gbx; gy2 += gby; }
+        else { gx2 += gax; gy2 += gay; gx0 += gbx; gy0 += gby; }
+    }
+    float *gb = gndc + b * (size_t)V * 3;
+    atomicAdd(gb + 3 * i0, gx0); atomicAdd(gb + 3 * i0 + 1, gy0); atomicAdd(gb + 3 * i0 + 2, dz0);
+    atomicAdd(gb + 3 * i1, gx1); atomicAdd(gb + 3 * i1 + 1, gy1); atomicAdd(gb + 3 * i1 + 2, dz1);
+    atomicAdd(gb + 3 * i2, gx2); atomicAdd(gb + 3 * i2 + 1, gy2); atomicAdd(gb + 3 * i2 + 2, dz2);
+}
+
+template <int K>
+void launch_raster_k(const float4 *rec, int B, int F, int S, float blur, int clip, int32_t *p2f, float *zbuf, float *bary,
+                     float *dists, hipStream_t s) {
+    const int tiles = st3d::cdiv(S, TILE);
+    raster_k_kernel<K><<<dim3(tiles, tiles, B), 256, 0, s>>>(rec, F, S, blur, clip, p2f, zbuf, bary, dists);
+}
+
+}  // namespace
+
+extern "C" int st3d_raster_soft_fwd(const float *face_records, int B, int F, int S, int K, float blur_radius, int clip_bary,
+                                    int32_t *pix_to_face, float *zbuf, float *bary, float *dists, st3d_stream_t stream) {
+    ST3D_CHECK_ARG(face_records && pix_to_face && zbuf && bary && dists);
+    ST3D_CHECK_ARG(B > 0 && F > 0 && S > 0 && K >= 1 && K <= 8 && blur_radius >= 0.f);
+    ST3D_CHECK_ARG(((uintptr_t)face_records & 15) == 0);
+    hipStream_t s = st3d::as_stream(stream);
+    const float4 *rec = reinterpret_cast<const float4 *>(face_records);
+    switch (K) {
+        case 1: launch_raster_k<1>(rec, B, F, S, blur_radius, clip_bary, pix_to_face, zbuf, bary, dists, s); break;
+        case 2: launch_raster_k<2>(rec, B, F, S, blur_radius, clip_bary, pix_to_face, zbuf, bary, dists, s); break;
+        case 3: launch_raster_k<3>(rec, B, F, S, blur_radius, clip_bary, pix_to_face, zbuf, bary, dists, s); break;
+        case 4: launch_raster_k<4>(rec, B, F, S, blur_radius, clip_bary, pix_to_face, zbuf, bary, dists, s); break;
+        case 5: launch_raster_k<5>(rec, B, F, S, blur_radius, clip_bary, pix_to_face, zbuf, bary, dists, s); break;
+        case 6: launch_raster_k<6>(rec, B, F, S, blur_radius, clip_bary, pix_to_face, zbuf, bary, dists, s); break;
+        case 7: launch_raster_k<7>(rec, B, F, S, blur_radius, clip_bary, pix_to_face, zbuf, bary, dists, s); break;
+        default: launch_raster_k<8>(rec, B, F, S, blur_radius, clip_bary, pix_to_face, zbuf, bary, dists, s); break;
+    }
+    ST3D_LAUNCH_CHECK();
+    return ST3D_OK;
+}
+
+extern "C" int st3d_shade_soft_fwd(const int32_t *pix_to_face, const float *bary, const float *zbuf, const float *dists,
+                                   const float *verts_uvs, const int32_t *faces_uvs, const float *texture, int B, int S, int T,
+                                   int K, float sigma, float gamma, const float *background, float *rgb, float *alpha,
+                                   st3d_stream_t stream) {
+    ST3D_CHECK_ARG(pix_to_face && bary && zbuf && dists && verts_uvs && faces_uvs && texture && background && rgb && alpha);
+    ST3D_CHECK_ARG(B > 0 && S > 0 && T > 1 && K >= 1 && sigma > 0.f && gamma > 0.f);
+    SoftArgs a{pix_to_face, bary, zbuf, dists, verts_uvs, faces_uvs, texture, B, S, T, K, sigma, gamma, background[0],
+               background[1], background[2]};
+    const size_t n = (size_t)B * S * S;
+    soft_shade_kernel<0><<<st3d::cdiv((long)n, 256), 256, 0, st3d::as_stream(stream)>>>(a, rgb, alpha, nullptr, nullptr, nullptr,
+                                                                                        nullptr, nullptr);
+    ST3D_LAUNCH_CHECK();
+    return ST3D_OK;
+}
+
+extern "C" int st3d_shade_soft_bwd(const float *grad_rgb, const int32_t *pix_to_face, const float *bary, const float *zbuf,
+                                   const float *dists, const float *verts_uvs, const int32_t *faces_uvs, const float *texture,
+                                   int B, int S, int T, int K, float sigma, float gamma, const float *background,
+                                   float *grad_texture, float *grad_bary, float *grad_zbuf, float *grad_dists,
+                                   st3d_stream_t stream) {
+    ST3D_CHECK_ARG(grad_rgb && pix_to_face && bary && zbuf && dists && verts_uvs && faces_uvs && texture && background);
+    ST3D_CHECK_ARG(grad_texture || grad_bary || grad_zbuf || grad_dists);
+    ST3D_CHECK_ARG(B > 0 && S > 0 && T > 1 && K >= 1 && sigma > 0.f && gamma > 0.f);
+    SoftArgs a{pix_to_face, bary, zbuf, dists, verts_uvs, faces_uvs, texture, B, S, T, K, sigma, gamma, background[0],
+               background[1], background[2]};
+    const size_t n = (size_t)B * S * S;
+    soft_shade_kernel<1><<<st3d::cdiv((long)n, 256), 256, 0, st3d::as_stream(stream)>>>(a, nullptr, nullptr, grad_rgb, grad_texture,
+                                                                                        grad_bary, grad_zbuf, grad_dists);
+    ST3D_LAUNCH_CHECK();
+    return ST3D_OK;
+}
+
+extern "C" int st3d_raster_soft_bwd(const float *grad_bary, const float *grad_zbuf, const float *grad_dists,
+                                    const int32_t *pix_to_face, const float *verts_ndc, const int32_t *faces, int B, int V,
+                                    int F, int S, int K, int clip_bary, float *grad_verts_ndc, st3d_stream_t stream) {
+    ST3D_CHECK_ARG(pix_to_face && verts_ndc && faces && grad_verts_ndc && (grad_bary || grad_zbuf || grad_dists));
+    ST3D_CHECK_ARG(B > 0 && V > 0 && F > 0 && S > 0 && K >= 1);
+    hipStream_t s = st3d::as_stream(stream);
+    ST3D_HIP(hipMemsetAsync(grad_verts_ndc, 0, (size_t)B * V * 3 * sizeof(float), s));
+    const size_t n = (size_t)B * S * S * K;
+    raster_k_bwd_kernel<<<st3d::cdiv((long)n, 256), 256, 0, s>>>(grad_bary, grad_zbuf, grad_dists, pix_to_face, verts_ndc, faces, B,
+                                                                  V, S, K, clip_bary, grad_verts_ndc);
+    ST3D_LAUNCH_CHECK();
+    return ST3D_OK;
+}

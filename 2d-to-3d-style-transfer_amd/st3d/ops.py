@@ -116,6 +116,68 @@ def mesh_reg(verts, target, topo, weights, want_grad=True):
     return out, g
 
 
+# ------------------------------------------------------------------ general soft renderer (K faces per pixel, blur)
+def raster_soft_fwd(verts_ndc, faces_i32, S, K, blur_radius=0.0, clip_bary=None):
+    """-> pix_to_face (B,S,S,K) int32, zbuf, bary (B,S,S,K,3), dists; clip_bary None = PyTorch3D default (blur > 0)."""
+    B, V, _ = verts_ndc.shape
+    F = faces_i32.shape[0]
+    dev = verts_ndc.device
+    if clip_bary is None:
+        clip_bary = blur_radius > 0.0
+    ws_bytes = _lib.load().st3d_raster_workspace_bytes(B, F)
+    rec = torch.empty((ws_bytes // 4,), dtype=F32, device=dev)
+    call("st3d_face_setup", dptr(verts_ndc, F32), dptr(faces_i32, I32), B, V, F, dptr(rec), ws_bytes, stream_ptr())
+    p2f = torch.empty((B, S, S, K), dtype=I32, device=dev)
+    zbuf = torch.empty((B, S, S, K), dtype=F32, device=dev)
+    bary = torch.empty((B, S, S, K, 3), dtype=F32, device=dev)
+    dists = torch.empty((B, S, S, K), dtype=F32, device=dev)
+    call("st3d_raster_soft_fwd", dptr(rec), B, F, S, int(K), float(blur_radius), 1 if clip_bary else 0, dptr(p2f), dptr(zbuf),
+         dptr(bary), dptr(dists), stream_ptr())
+    return p2f, zbuf, bary, dists
+
+
+def _bg3(background):
+    return (ctypes.c_float * 3)(*[float(x) for x in background])
+
+
+def shade_soft_fwd(frag, verts_uvs, faces_uvs_i32, texture, sigma=1e-4, gamma=1e-4, background=(1.0, 1.0, 1.0)):
+    p2f, zbuf, bary, dists = frag
+    B, S, _, K = p2f.shape
+    rgb = torch.empty((B, 3, S, S), dtype=F32, device=p2f.device)
+    alpha = torch.empty((B, 1, S, S), dtype=F32, device=p2f.device)
+    call("st3d_shade_soft_fwd", dptr(p2f, I32), dptr(bary, F32), dptr(zbuf, F32), dptr(dists, F32), dptr(verts_uvs, F32),
+         dptr(faces_uvs_i32, I32), dptr(texture, F32), B, S, texture.shape[0], K, float(sigma), float(gamma), _bg3(background),
+         dptr(rgb), dptr(alpha), stream_ptr())
+    return rgb, alpha
+
+
+def shade_soft_bwd(grad_rgb, frag, verts_uvs, faces_uvs_i32, texture, sigma=1e-4, gamma=1e-4, background=(1.0, 1.0, 1.0),
+                   want_texture=True, want_geometry=True):
+    """-> (grad_texture (T,T,3) | None, (grad_bary, grad_zbuf, grad_dists) | None)"""
+    p2f, zbuf, bary, dists = frag
+    B, S, _, K = p2f.shape
+    T = texture.shape[0]
+    dev = p2f.device
+    gt = torch.zeros((T, T, 3), dtype=F32, device=dev) if want_texture else None
+    gb = torch.empty((B, S, S, K, 3), dtype=F32, device=dev) if want_geometry else None
+    gz = torch.empty((B, S, S, K), dtype=F32, device=dev) if want_geometry else None
+    gd = torch.empty((B, S, S, K), dtype=F32, device=dev) if want_geometry else None
+    call("st3d_shade_soft_bwd", dptr(grad_rgb.contiguous(), F32), dptr(p2f, I32), dptr(bary, F32), dptr(zbuf, F32),
+         dptr(dists, F32), dptr(verts_uvs, F32), dptr(faces_uvs_i32, I32), dptr(texture, F32), B, S, T, K, float(sigma),
+         float(gamma), _bg3(background), dptr(gt), dptr(gb), dptr(gz), dptr(gd), stream_ptr())
+    return gt, ((gb, gz, gd) if want_geometry else None)
+
+
+def raster_soft_bwd(grads, p2f, verts_ndc, faces_i32, clip_bary):
+    gb, gz, gd = grads
+    B, V, _ = verts_ndc.shape
+    S, K = p2f.shape[1], p2f.shape[3]
+    g = torch.empty((B, V, 3), dtype=F32, device=verts_ndc.device)
+    call("st3d_raster_soft_bwd", dptr(gb, F32), dptr(gz, F32), dptr(gd, F32), dptr(p2f, I32), dptr(verts_ndc, F32),
+         dptr(faces_i32, I32), B, V, faces_i32.shape[0], S, K, 1 if clip_bary else 0, dptr(g), stream_ptr())
+    return g
+
+
 def apply_background(img, mask, bg=None):
     B, _, S, _ = img.shape
     out = torch.empty_like(img)

@@ -7,8 +7,11 @@ like the reference.  Rendering itself is NOT a per-camera Python loop of ~20 sma
 upstream: all views of a batch go through four HIP launches (project, face setup + tile
 raster, fused shade) and the backward is one launch (texture scatter).
 
-Only what the reference configures is implemented: blur_radius=0, faces_per_pixel=1,
-AmbientLights, FoV perspective cameras with default fov/znear/zfar.
+The reference's own configuration (blur_radius=0, faces_per_pixel=1, default BlendParams;
+first_approach.py:107) runs on the specialised hard kernels.  Any other RasterizationSettings /
+BlendParams (K <= 8 faces per pixel, blur_radius > 0, clipped barycentrics, sigma/gamma/background)
+runs on the general soft rasteriser + softmax blend (csrc/soft.hip).  Lights:
+AmbientLights only; cameras: FoV perspective with default fov/znear/zfar.
 """
 import math
 
@@ -214,11 +217,44 @@ class RotateAxisAngle:
 
 
 class RasterizationSettings:
-    def __init__(self, image_size=256, blur_radius=0.0, faces_per_pixel=1, **kw):
-        if blur_radius != 0.0 or faces_per_pixel != 1:
-            raise NotImplementedError("the reference fixes blur_radius=0.0, faces_per_pixel=1 "
-                                      "(first_approach.py:107); the soft rasteriser is a later row")
-        self.image_size, self.blur_radius, self.faces_per_pixel = int(image_size), 0.0, 1
+    """PyTorch3D RasterizationSettings: image_size, blur_radius, faces_per_pixel, clip_barycentric_coords
+    (None = clip iff blur_radius > 0, the PyTorch3D default).  bin_size / max_faces_per_bin only pick
+    PyTorch3D's binning strategy and are accepted and ignored; perspective_correct must stay on and
+    cull_backfaces off (the values the reference runs with)."""
+    MAX_FACES_PER_PIXEL = 8
+
+    def __init__(self, image_size=256, blur_radius=0.0, faces_per_pixel=1, bin_size=None, max_faces_per_bin=None,
+                 perspective_correct=None, clip_barycentric_coords=None, cull_backfaces=False, **kw):
+        if isinstance(image_size, (tuple, list)):
+            if len(image_size) != 2 or image_size[0] != image_size[1]:
+                raise NotImplementedError("square images only")
+            image_size = image_size[0]
+        if perspective_correct is False or cull_backfaces:
+            raise NotImplementedError("perspective_correct=False / cull_backfaces=True are not implemented")
+        if not 1 <= int(faces_per_pixel) <= self.MAX_FACES_PER_PIXEL:
+            raise NotImplementedError(f"faces_per_pixel must be in 1..{self.MAX_FACES_PER_PIXEL}")
+        if blur_radius < 0.0:
+            raise ValueError("blur_radius must be >= 0")
+        self.image_size, self.blur_radius, self.faces_per_pixel = int(image_size), float(blur_radius), int(faces_per_pixel)
+        self.clip_barycentric_coords = (self.blur_radius > 0.0) if clip_barycentric_coords is None \
+            else bool(clip_barycentric_coords)
+
+    @property
+    def is_hard(self):
+        return self.faces_per_pixel == 1 and self.blur_radius == 0.0 and not self.clip_barycentric_coords
+
+
+class BlendParams:
+    """PyTorch3D BlendParams (sigma, gamma, background_color) for softmax_rgb_blend."""
+
+    def __init__(self, sigma=1e-4, gamma=1e-4, background_color=(1.0, 1.0, 1.0)):
+        self.sigma, self.gamma = float(sigma), float(gamma)
+        bg = torch.as_tensor(background_color, dtype=torch.float32).reshape(-1).tolist()
+        if len(bg) != 3:
+            raise ValueError("background_color must have 3 components")
+        self.background_color = tuple(bg)
+        if self.sigma <= 0.0 or self.gamma <= 0.0:
+            raise ValueError("sigma and gamma must be positive")
 
 
 class AmbientLights:
@@ -234,8 +270,9 @@ class MeshRasterizer:
 
 
 class SoftPhongShader:
-    def __init__(self, device="cpu", cameras=None, lights=None, **kw):
+    def __init__(self, device="cpu", cameras=None, lights=None, materials=None, blend_params=None, **kw):
         self.cameras, self.lights = cameras, lights
+        self.blend_params = blend_params if blend_params is not None else BlendParams()
 
 
 class _RenderFn(torch.autograd.Function):
@@ -276,18 +313,76 @@ class _RenderFn(torch.autograd.Function):
         return gverts, gtex, None, None, None, None, None, None
 
 
-def render_views(meshes, R, T, image_size):
-    """All B views in one batch of launches -> (rgb (B,3,S,S), mask (B,1,S,S))."""
+class _SoftRenderFn(torch.autograd.Function):
+    """General path: K faces per pixel, blur_radius, softmax_rgb_blend -> (rgb (B,3,S,S), alpha (B,1,S,S)).
+    Gradients flow from rgb to the texture and, through barycentrics, depth and the signed edge distance, to
+    the vertices; alpha is returned without a gradient (the reference only ever thresholds it, utils.py:72)."""
+
+    @staticmethod
+    def forward(ctx, verts, tex_map, faces_i32, verts_uvs, faces_uvs_i32, R, T, S, K, blur, clip, sigma, gamma, bg):
+        v = verts.detach().to(torch.float32).contiguous()
+        tex = tex_map.detach().to(torch.float32).reshape(tex_map.shape[-3], tex_map.shape[-2], 3).contiguous()
+        if tex.shape[0] != tex.shape[1]:
+            raise NotImplementedError("square texture maps only (the reference resizes to size x size)")
+        uvs = verts_uvs.detach().to(torch.float32).reshape(-1, 2).contiguous()
+        ndc = ops.project_verts(v, R, T)
+        frag = ops.raster_soft_fwd(ndc, faces_i32, S, K, blur, clip)
+        rgb, alpha = ops.shade_soft_fwd(frag, uvs, faces_uvs_i32, tex, sigma, gamma, bg)
+        ctx.frag, ctx.uvs, ctx.fuv, ctx.tex = frag, uvs, faces_uvs_i32, tex
+        ctx.blend = (sigma, gamma, bg)
+        ctx.clip = clip
+        ctx.tex_shape, ctx.verts_shape = tex_map.shape, verts.shape
+        ctx.geom = (v, ndc, faces_i32, R, T)
+        ctx.mark_non_differentiable(alpha)
+        return rgb, alpha
+
+    @staticmethod
+    def backward(ctx, grad_rgb, _grad_alpha):
+        need_v, need_t = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        gtex = gverts = None
+        if need_v or need_t:
+            sigma, gamma, bg = ctx.blend
+            gt, geo = ops.shade_soft_bwd(grad_rgb.to(torch.float32), ctx.frag, ctx.uvs, ctx.fuv, ctx.tex, sigma, gamma, bg,
+                                         want_texture=need_t, want_geometry=need_v)
+            if need_t:
+                gtex = gt.reshape(ctx.tex_shape)
+            if need_v:
+                v, ndc, faces_i32, R, T = ctx.geom
+                gndc = ops.raster_soft_bwd(geo, ctx.frag[0], ndc, faces_i32, ctx.clip)
+                gverts = ops.project_verts_bwd(v, R, T, gndc).reshape(ctx.verts_shape)
+        return (gverts, gtex) + (None,) * 12
+
+
+def uses_hard_path(raster_settings, blend_params):
+    """True for the reference's own configuration (K=1, blur 0, unclipped, default BlendParams): there
+    softmax_rgb_blend reduces to texel-or-white and the specialised kernels apply."""
+    rs, bp = raster_settings, blend_params
+    if rs is not None and not rs.is_hard:
+        return False
+    return bp is None or (bp.sigma, bp.gamma, bp.background_color) == (1e-4, 1e-4, (1.0, 1.0, 1.0))
+
+
+def render_views(meshes, R, T, image_size, raster_settings=None, blend_params=None):
+    """All B views in one batch of launches -> (rgb (B,3,S,S), coverage (B,1,S,S)).  Coverage is the 0/1 mask on
+    the hard path and softmax_rgb_blend's alpha on the soft path; both satisfy ``coverage > 0`` == covered."""
     tex = meshes.textures
     dev = meshes.device
-    return _RenderFn.apply(meshes.verts_packed(), tex.maps_padded(), meshes.faces_i32(), tex.verts_uvs_padded(),
-                           tex.faces_uvs_i32(), R.to(dev), T.to(dev), int(image_size))
+    rs, bp = raster_settings, blend_params
+    if uses_hard_path(rs, bp):
+        # K=1, blur 0: the blend weight cancels and the pixel is the sampled texel itself (SURVEY.md A.4)
+        return _RenderFn.apply(meshes.verts_packed(), tex.maps_padded(), meshes.faces_i32(), tex.verts_uvs_padded(),
+                               tex.faces_uvs_i32(), R.to(dev), T.to(dev), int(image_size))
+    bp = bp if bp is not None else BlendParams()
+    rs = rs if rs is not None else RasterizationSettings(image_size=image_size)
+    return _SoftRenderFn.apply(meshes.verts_packed(), tex.maps_padded(), meshes.faces_i32(), tex.verts_uvs_padded(),
+                               tex.faces_uvs_i32(), R.to(dev), T.to(dev), int(image_size), rs.faces_per_pixel,
+                               rs.blur_radius, rs.clip_barycentric_coords, bp.sigma, bp.gamma, bp.background_color)
 
 
 class MeshRenderer:
     """``renderer(meshes_world=mesh, cameras=camera)`` -> (n,S,S,4) RGBA like PyTorch3D's
     MeshRenderer (utils.py:69); ``render_meshes`` in the drop-in utils.py calls
-    ``render_views`` directly and skips the RGBA repack."""
+    ``render`` and skips the RGBA repack."""
 
     def __init__(self, rasterizer, shader):
         self.rasterizer, self.shader = rasterizer, shader
@@ -296,13 +391,22 @@ class MeshRenderer:
     def image_size(self):
         return self.rasterizer.raster_settings.image_size
 
-    def __call__(self, meshes_world, cameras=None, **kw):
+    @property
+    def is_hard(self):
+        return uses_hard_path(self.rasterizer.raster_settings, getattr(self.shader, "blend_params", None))
+
+    def render(self, meshes_world, cameras=None):
+        """-> (rgb (n,3,S,S), coverage (n,1,S,S)) under this renderer's raster settings and blend params."""
         cameras = cameras if cameras is not None else self.rasterizer.cameras
         R, T = join_cameras(cameras)
-        rgb, mask = render_views(meshes_world, R, T, self.image_size)
-        # alpha of softmax_rgb_blend with K=1 is in [0.5,1) on covered pixels, 0 elsewhere; only
-        # (alpha > 0) is ever consumed (utils.py:72), so the mask stands in for it
-        return torch.cat([rgb, mask], dim=1).permute(0, 2, 3, 1)
+        return render_views(meshes_world, R, T, self.image_size, self.rasterizer.raster_settings,
+                            getattr(self.shader, "blend_params", None))
+
+    def __call__(self, meshes_world, cameras=None, **kw):
+        rgb, cov = self.render(meshes_world, cameras)
+        # hard path: alpha of softmax_rgb_blend with K=1 is in [0.5,1) on covered pixels, 0 elsewhere; only
+        # (alpha > 0) is ever consumed (utils.py:72), so the 0/1 mask stands in for it.  Soft path: the real alpha.
+        return torch.cat([rgb, cov], dim=1).permute(0, 2, 3, 1)
 
     def to(self, *a, **k):
         return self

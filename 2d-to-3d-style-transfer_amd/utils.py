@@ -79,9 +79,10 @@ def tensor_to_image(tensor):
 
 # Render the content tensor
 def render_meshes(renderer, meshes, cameras):
-    R, T = _render.join_cameras(cameras)
-    tensors, object_masks = _render.render_views(meshes, R, T, renderer.image_size)
-    return tensors, object_masks      # (BATCH, 3, H, W), (BATCH, 1, H, W) with mask = alpha > 0
+    tensors, coverage = renderer.render(meshes, cameras)
+    if not renderer.is_hard:
+        coverage = (coverage.detach() > 0).float()      # soft settings: alpha -> mask (reference :72)
+    return tensors, coverage      # (BATCH, 3, H, W), (BATCH, 1, H, W) with mask = alpha > 0
 
 
 # Save final optimized images

@@ -92,6 +92,30 @@ int st3d_project_verts_bwd(const float *verts, int V, const float *R, const floa
                            float inv_tan_half_fov, const float *grad_verts_ndc, int accumulate,
                            float *grad_verts, st3d_stream_t stream);
 
+/* ---- general soft renderer (the reference fixes K = 1, blur = 0 and uses the entry points above):
+ * K = faces_per_pixel <= 8 nearest faces per pixel, blur_radius >= 0, barycentric clipping (PyTorch3D clips when
+ * blur_radius > 0), softmax_rgb_blend over the K layers with sigma / gamma / background (host float[3]).
+ * Fragment arrays are (B,S,S,K[,3]), depth-sorted, -1 filled. */
+int st3d_face_setup(const float *verts_ndc, const int32_t *faces, int B, int V, int F, void *face_records,
+                    size_t records_bytes /* >= st3d_raster_workspace_bytes */, st3d_stream_t stream);
+int st3d_raster_soft_fwd(const float *face_records, int B, int F, int S, int K, float blur_radius, int clip_bary,
+                         int32_t *pix_to_face, float *zbuf, float *bary, float *dists, st3d_stream_t stream);
+int st3d_shade_soft_fwd(const int32_t *pix_to_face, const float *bary, const float *zbuf, const float *dists,
+                        const float *verts_uvs, const int32_t *faces_uvs, const float *texture, int B, int S, int T,
+                        int K, float sigma, float gamma, const float *background, float *rgb, float *alpha,
+                        st3d_stream_t stream);
+/* grad_rgb (B,3,S,S) -> grad_texture (T,T,3) accumulated, per-layer grad_bary (B,S,S,K,3), grad_zbuf, grad_dists
+ * (B,S,S,K); any output may be NULL */
+int st3d_shade_soft_bwd(const float *grad_rgb, const int32_t *pix_to_face, const float *bary, const float *zbuf,
+                        const float *dists, const float *verts_uvs, const int32_t *faces_uvs, const float *texture,
+                        int B, int S, int T, int K, float sigma, float gamma, const float *background,
+                        float *grad_texture, float *grad_bary, float *grad_zbuf, float *grad_dists,
+                        st3d_stream_t stream);
+/* PyTorch3D RasterizeMeshesBackward: (grad_bary, grad_zbuf, grad_dists) -> grad_verts_ndc (B,V,3), zeroed by the call */
+int st3d_raster_soft_bwd(const float *grad_bary, const float *grad_zbuf, const float *grad_dists,
+                         const int32_t *pix_to_face, const float *verts_ndc, const int32_t *faces, int B, int V, int F,
+                         int S, int K, int clip_bary, float *grad_verts_ndc, st3d_stream_t stream);
+
 /* apply_background, utils.py:19-30: out = img*mask + bg*(1-mask); bg (B,3,S,S) or, with
  * bg_batch == 1, one (3,S,S) image broadcast over the batch.  Optional grad path is the
  * same kernel applied to the gradient with bg = NULL (out = g*mask). */

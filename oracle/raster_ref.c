@@ -391,3 +391,82 @@ void ref_project_verts_bwd(const float *verts, int V, const float *R, const floa
         grad_verts[3 * v + 2] += dxv * R[6] + dyv * R[7] + dzv * R[8];
     }
 }
+
+/* ---------------------------------------------------------------- general soft rasteriser
+ * K = faces_per_pixel nearest faces per pixel, blur_radius >= 0, optional barycentric clipping
+ * (PyTorch3D clips when blur_radius > 0 unless told otherwise): the general form of ref_rasterize
+ * the reference does NOT use (it fixes K = 1, blur = 0) but BASELINE.json's north star names.
+ * Outputs (S,S,K) sorted by ascending depth, -1 filled.  PARITY UNPINNED (see the header). */
+void ref_rasterize_k(const float *verts_ndc, const int32_t *faces, int F, int S, int K,
+                     float blur_radius, int clip_bary, int nthreads,
+                     int32_t *pix_to_face, float *zbuf, float *bary, float *dists)
+{
+    const float pad = sqrtf(blur_radius);
+    (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+    for (int yi = 0; yi < S; ++yi) {
+        const float yf = pix_to_ndc(S - 1 - yi, S);
+        for (int xi = 0; xi < S; ++xi) {
+            const float xf = pix_to_ndc(S - 1 - xi, S);
+            int qf[16]; float qz[16], qd[16], qb[16][3];
+            int qn = 0;
+            for (int f = 0; f < F; ++f) {
+                const int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
+                const float x0 = verts_ndc[3 * i0], y0 = verts_ndc[3 * i0 + 1], z0 = verts_ndc[3 * i0 + 2];
+                const float x1 = verts_ndc[3 * i1], y1 = verts_ndc[3 * i1 + 1], z1 = verts_ndc[3 * i1 + 2];
+                const float x2 = verts_ndc[3 * i2], y2 = verts_ndc[3 * i2 + 1], z2 = verts_ndc[3 * i2 + 2];
+                const float xmin = fminf(x0, fminf(x1, x2)) - pad, xmax = fmaxf(x0, fmaxf(x1, x2)) + pad;
+                const float ymin = fminf(y0, fminf(y1, y2)) - pad, ymax = fmaxf(y0, fmaxf(y1, y2)) + pad;
+                if (xf > xmax || xf < xmin || yf > ymax || yf < ymin) continue;
+                if (fmaxf(z0, fmaxf(z1, z2)) < K_EPS) continue;
+                const float face_area = edge_fn(x2, y2, x0, y0, x1, y1);
+                if (face_area <= K_EPS && face_area >= -K_EPS) continue;
+                const float area = face_area + K_EPS;
+                const float w0 = edge_fn(xf, yf, x1, y1, x2, y2) / area;
+                const float w1 = edge_fn(xf, yf, x2, y2, x0, y0) / area;
+                const float w2 = edge_fn(xf, yf, x0, y0, x1, y1) / area;
+                const float t0 = w0 * z1 * z2, t1 = z0 * w1 * z2, t2 = z0 * z1 * w2;
+                const float den = fmaxf(t0 + t1 + t2, K_EPS);
+                const float b0 = t0 / den, b1 = t1 / den, b2 = t2 / den;
+                float c0 = b0, c1 = b1, c2 = b2;
+                if (clip_bary) {
+                    c0 = fminf(fmaxf(b0, 0.f), 1.f); c1 = fminf(fmaxf(b1, 0.f), 1.f); c2 = fminf(fmaxf(b2, 0.f), 1.f);
+                    const float s = fmaxf(c0 + c1 + c2, K_EPS);
+                    c0 /= s; c1 /= s; c2 /= s;
+                }
+                const float pz = c0 * z0 + c1 * z1 + c2 * z2;
+                if (pz < 0.f) continue;
+                const int inside = (b0 > 0.f) && (b1 > 0.f) && (b2 > 0.f);
+                const float d01 = point_line_dist2(xf, yf, x0, y0, x1, y1);
+                const float d12 = point_line_dist2(xf, yf, x1, y1, x2, y2);
+                const float d20 = point_line_dist2(xf, yf, x2, y2, x0, y0);
+                const float d = fminf(d01, fminf(d12, d20));
+                if (!inside && d >= blur_radius) continue;
+                const float sd = inside ? -d : d;
+                /* insert into the K-best list (ascending z; equal z keeps the earlier face first) */
+                int pos = qn;
+                while (pos > 0 && pz < qz[pos - 1]) --pos;
+                if (pos >= K) continue;
+                const int last = (qn < K) ? qn : K - 1;
+                for (int j = last; j > pos; --j) {
+                    qf[j] = qf[j - 1]; qz[j] = qz[j - 1]; qd[j] = qd[j - 1];
+                    qb[j][0] = qb[j - 1][0]; qb[j][1] = qb[j - 1][1]; qb[j][2] = qb[j - 1][2];
+                }
+                qf[pos] = f; qz[pos] = pz; qd[pos] = sd; qb[pos][0] = c0; qb[pos][1] = c1; qb[pos][2] = c2;
+                if (qn < K) ++qn;
+            }
+            const size_t p = ((size_t)yi * S + xi) * K;
+            for (int k = 0; k < K; ++k) {
+                if (k < qn) {
+                    pix_to_face[p + k] = qf[k]; zbuf[p + k] = qz[k]; dists[p + k] = qd[k];
+                    bary[3 * (p + k)] = qb[k][0]; bary[3 * (p + k) + 1] = qb[k][1]; bary[3 * (p + k) + 2] = qb[k][2];
+                } else {
+                    pix_to_face[p + k] = -1; zbuf[p + k] = -1.f; dists[p + k] = -1.f;
+                    bary[3 * (p + k)] = -1.f; bary[3 * (p + k) + 1] = -1.f; bary[3 * (p + k) + 2] = -1.f;
+                }
+            }
+        }
+    }
+}

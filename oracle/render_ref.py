@@ -49,8 +49,10 @@ def lib():
         _lib.ref_uv_to_bary_grad.argtypes = [F32P, I32P, F32P, I32P, ctypes.c_int, F32P]
         _lib.ref_raster_bwd.argtypes = [F32P, I32P, F32P, I32P, ctypes.c_int, F64P]
         _lib.ref_project_verts_bwd.argtypes = [F32P, ctypes.c_int, F32P, F32P, ctypes.c_float, F64P, F64P]
+        _lib.ref_rasterize_k.argtypes = [F32P, I32P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int,
+                                         ctypes.c_int, I32P, F32P, F32P, F32P]
         for f in ("ref_project_verts", "ref_rasterize", "ref_shade_fwd", "ref_shade_bwd", "ref_adam_step",
-                  "ref_uv_to_bary_grad", "ref_raster_bwd", "ref_project_verts_bwd"):
+                  "ref_uv_to_bary_grad", "ref_raster_bwd", "ref_project_verts_bwd", "ref_rasterize_k"):
             getattr(_lib, f).restype = None
     return _lib
 
@@ -156,6 +158,23 @@ def rasterize(verts_ndc, faces, S, blur_radius=0.0, nthreads=1):
     dists = np.empty((S, S), np.float32)
     lib().ref_rasterize(_p(verts_ndc, F32P), _p(faces, I32P), faces.shape[0], S, blur_radius, nthreads,
                         _p(p2f, I32P), _p(zbuf, F32P), _p(bary, F32P), _p(dists, F32P))
+    return p2f, zbuf, bary, dists
+
+
+def rasterize_k(verts_ndc, faces, S, K, blur_radius=0.0, clip_bary=None, nthreads=1):
+    """General soft rasteriser: (S,S,K) fragments sorted by depth.  clip_bary=None follows
+    PyTorch3D's default (clip when blur_radius > 0)."""
+    assert 1 <= K <= 16
+    if clip_bary is None:
+        clip_bary = blur_radius > 0.0
+    verts_ndc = _f32(verts_ndc)
+    faces = _i32(faces)
+    p2f = np.empty((S, S, K), np.int32)
+    zbuf = np.empty((S, S, K), np.float32)
+    bary = np.empty((S, S, K, 3), np.float32)
+    dists = np.empty((S, S, K), np.float32)
+    lib().ref_rasterize_k(_p(verts_ndc, F32P), _p(faces, I32P), faces.shape[0], S, K, blur_radius, int(bool(clip_bary)),
+                          nthreads, _p(p2f, I32P), _p(zbuf, F32P), _p(bary, F32P), _p(dists, F32P))
     return p2f, zbuf, bary, dists
 
 

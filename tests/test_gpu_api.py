@@ -382,3 +382,71 @@ def test_mesh_without_uvs_gets_synthesised_ones(mods, golden_dir, tmp_path):
              "--batch_size", "2", "--epochs", "2", "--output_path", outp, "--seed", "0", "--save_every", "0"])
     log = open(os.path.join(outp, "log.txt")).read().splitlines()
     assert len(log) == 3 and all(np.isfinite(float(line.split("Loss ")[1])) for line in log[1:])
+
+
+def test_soft_renderer_settings_match_oracle_through_the_api(mods, cow):
+    """RasterizationSettings(blur_radius > 0, faces_per_pixel = 4) + BlendParams through MeshRenderer (the PyTorch3D
+    configuration space outside the reference's fixed K=1 / blur 0): RGBA against the torch restatement of
+    softmax_rgb_blend at the same coverage, autograd d/d texture and d/d verts against fp64 autograd."""
+    _, _, U, dev = mods
+    from oracle import render_ref as rr
+    from oracle import soft_ref as SR
+    from st3d.render import (BlendParams, FoVPerspectiveCameras, MeshRasterizer, MeshRenderer, RasterizationSettings,
+                             SoftPhongShader)
+    S, Tn, B, K = 64, 24, 2, 4
+    blur, sigma, gamma, bg = 1e-3, 1e-3, 1e-2, (0.2, 0.5, 0.9)
+    rng = np.random.default_rng(3)
+    tex_np = rng.random((Tn, Tn, 3), dtype=np.float32)
+    g = torch.Generator().manual_seed(11)
+    elev, azim = rr.random_camera_angles(B, lambda k: torch.rand(k, generator=g).numpy())
+    R, Tt = rr.look_at_view_transform(2.10, elev, azim, at=(0, 0.10, 0.25))
+    verts = torch.from_numpy(cow["verts"]).to(dev).requires_grad_(True)
+    tex = torch.from_numpy(tex_np)[None].to(dev).requires_grad_(True)
+    mesh = U.build_mesh(torch.from_numpy(cow["verts_uvs"])[None].to(dev),
+                        torch.from_numpy(cow["faces_uvs"].astype(np.int64))[None].to(dev), tex, verts,
+                        torch.from_numpy(cow["faces"].astype(np.int64)).to(dev))
+    rs = RasterizationSettings(image_size=S, blur_radius=blur, faces_per_pixel=K)
+    assert rs.clip_barycentric_coords and not rs.is_hard
+    renderer = MeshRenderer(MeshRasterizer(None, rs), SoftPhongShader(blend_params=BlendParams(sigma, gamma, bg)))
+    cams = FoVPerspectiveCameras(R=torch.from_numpy(R), T=torch.from_numpy(Tt), device=dev)
+    rgba = renderer(meshes_world=mesh, cameras=cams)
+    assert rgba.shape == (B, S, S, 4)
+    gimg = rng.standard_normal((B, S, S, 3)).astype(np.float32)
+    (rgba[..., :3] * torch.from_numpy(gimg).to(dev)).sum().backward()
+    # forward against the fp64 restatement at the GPU's coverage (bit-exact against the C oracle in test_gpu_kernels)
+    from st3d import ops
+    ndc = ops.project_verts(verts.detach(), cams.R, cams.T)
+    frag = ops.raster_soft_fwd(ndc, mesh.faces_i32(), S, K, blur, True)
+    p2f = frag[0].cpu().long()
+    with torch.no_grad():
+        for b in range(B):
+            r, a = SR.soft_render(torch.from_numpy(cow["verts"]).double(), torch.from_numpy(R[b]).double(),
+                                  torch.from_numpy(Tt[b]).double(), torch.from_numpy(cow["faces"]).long(), p2f[b],
+                                  torch.from_numpy(cow["verts_uvs"]).double(), torch.from_numpy(cow["faces_uvs"]).long(),
+                                  torch.from_numpy(tex_np).double(), S, True, sigma, gamma, bg)
+            np.testing.assert_allclose(rgba[b, ..., :3].detach().cpu().numpy(), r.permute(1, 2, 0).numpy(), atol=2e-5)
+            np.testing.assert_allclose(rgba[b, ..., 3].detach().cpu().numpy(), a.numpy(), atol=2e-5)
+    # autograd wiring: the same kernels called directly (their gradients are pinned to fp64 autograd in
+    # test_gpu_kernels.test_soft_shade_forward_and_backward_match_oracle); atomics reorder, hence not bitwise
+    gt, geo = ops.shade_soft_bwd(torch.from_numpy(gimg).to(dev).permute(0, 3, 1, 2).contiguous(), frag,
+                                 torch.from_numpy(cow["verts_uvs"]).to(dev), mesh.textures.faces_uvs_i32(),
+                                 tex.detach()[0].contiguous(), sigma, gamma, bg)
+    gv = ops.project_verts_bwd(verts.detach(), cams.R, cams.T, ops.raster_soft_bwd(geo, frag[0], ndc, mesh.faces_i32(), True))
+    assert float((tex.grad[0] - gt).norm() / gt.norm()) <= 1e-5
+    assert float((verts.grad - gv).norm() / gv.norm()) <= 1e-5
+    # drop-in render_meshes thresholds alpha into the reference's mask (utils.py:72)
+    with torch.no_grad():
+        cur, masks = U.render_meshes(renderer, mesh, cams)
+    assert set(torch.unique(masks).tolist()) <= {0.0, 1.0}
+    assert torch.equal(masks[:, 0] > 0, rgba[..., 3].detach() > 0)
+    # K=1 / blur 0 with a coloured background runs on the general kernels and agrees with the hard path + background
+    hard = MeshRenderer(MeshRasterizer(None, RasterizationSettings(image_size=S)), SoftPhongShader())
+    soft1 = MeshRenderer(MeshRasterizer(None, RasterizationSettings(image_size=S)),
+                         SoftPhongShader(blend_params=BlendParams(background_color=bg)))
+    assert hard.is_hard and not soft1.is_hard
+    with torch.no_grad():
+        h_rgb, h_mask = hard.render(mesh, cams)
+        s_rgb, s_cov = soft1.render(mesh, cams)
+    bgt = torch.tensor(bg, device=dev).view(1, 3, 1, 1)
+    np.testing.assert_allclose(s_rgb.cpu().numpy(), (h_rgb * h_mask + bgt * (1 - h_mask)).cpu().numpy(), atol=2e-6)
+    assert torch.equal(s_cov > 0, h_mask > 0)

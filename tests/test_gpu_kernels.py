@@ -371,3 +371,94 @@ def test_wino_fused_pool_and_unpool(dev, ops, N, Cin, Cout, H, W):
     assert none_full is None and torch.equal(pd3, pd) and torch.equal(idx3, idx)
     gx = ops.wino_dgrad_unpool(gp.float().to(dev), idx, pd, ud, Cin)
     _scale_close(gx, x.grad, 6e-5, "wino dgrad_unpool")
+
+
+# ---------------------------------------------------------------------------- general soft renderer (K faces / pixel, blur)
+@pytest.mark.parametrize("K,blur,clip", [(1, 0.0, False), (3, 0.0, False), (4, 2e-4, True), (8, 1e-3, True)])
+def test_soft_raster_matches_oracle(dev, ops, cow, K, blur, clip):
+    """(B,S,S,K) fragments bit-exact vs oracle/raster_ref.c:ref_rasterize_k (same operation order, no FMA contraction)."""
+    from oracle import render_ref as rr
+    S = 72
+    R, T = _cams(2, seed=K)
+    verts = torch.from_numpy(cow["verts"]).to(dev)
+    faces = torch.from_numpy(cow["faces"]).to(dev)
+    ndc = ops.project_verts(verts, torch.from_numpy(R).to(dev), torch.from_numpy(T).to(dev))
+    p2f, zbuf, bary, dists = ops.raster_soft_fwd(ndc, faces, S, K, blur, clip)
+    for b in range(2):
+        rp, rz, rb, rd = rr.rasterize_k(rr.project_verts(cow["verts"], R[b], T[b]), cow["faces"], S, K, blur, clip, nthreads=8)
+        np.testing.assert_array_equal(p2f[b].cpu().numpy(), rp)
+        np.testing.assert_array_equal(zbuf[b].cpu().numpy(), rz)
+        np.testing.assert_array_equal(bary[b].cpu().numpy(), rb)
+        np.testing.assert_array_equal(dists[b].cpu().numpy(), rd)
+        if K > 1:
+            assert ((rp[..., 1] >= 0).sum() > 0.02 * S * S)            # second layers exist (back faces of the cow)
+    if K == 1 and blur == 0.0:      # the general kernel reproduces the specialised hard rasteriser
+        h = ops.raster_fwd(ndc, faces, S)
+        assert torch.equal(h[0], p2f[..., 0]) and torch.equal(h[1], zbuf[..., 0]) and torch.equal(h[3], dists[..., 0])
+
+
+@pytest.mark.parametrize("K,blur,sigma,gamma", [(1, 0.0, 1e-4, 1e-4), (4, 3e-4, 1e-4, 1e-4), (3, 1e-3, 1e-3, 1e-2)])
+def test_soft_shade_forward_and_backward_match_oracle(dev, ops, cow, K, blur, sigma, gamma):
+    """softmax_rgb_blend over K layers: pixels against the torch restatement; d/d texture, d/d (bary, depth, signed
+    edge distance) and d/d vertices against fp64 autograd evaluated on the same fragments."""
+    from oracle import render_ref as rr
+    from oracle import soft_ref as SR
+    S, Tn, B = 64, 24, 2
+    bg = (0.2, 0.5, 0.9)
+    R, T = _cams(B, seed=7)
+    rng = np.random.default_rng(1)
+    tex = rng.random((Tn, Tn, 3), dtype=np.float32)
+    verts = torch.from_numpy(cow["verts"]).to(dev)
+    faces = torch.from_numpy(cow["faces"]).to(dev)
+    uvs = torch.from_numpy(cow["verts_uvs"]).to(dev)
+    fuv = torch.from_numpy(cow["faces_uvs"]).to(dev)
+    texd = torch.from_numpy(tex).to(dev)
+    Rd, Td = torch.from_numpy(R).to(dev), torch.from_numpy(T).to(dev)
+    clip = blur > 0
+    ndc = ops.project_verts(verts, Rd, Td)
+    frag = ops.raster_soft_fwd(ndc, faces, S, K, blur, clip)
+    rgb, alpha = ops.shade_soft_fwd(frag, uvs, fuv, texd, sigma, gamma, bg)
+    g = rng.standard_normal((B, 3, S, S)).astype(np.float32)
+    gt, geo = ops.shade_soft_bwd(torch.from_numpy(g).to(dev), frag, uvs, fuv, texd, sigma, gamma, bg)
+    gndc = ops.raster_soft_bwd(geo, frag[0], ndc, faces, clip)
+    gverts = ops.project_verts_bwd(verts, Rd, Td, gndc)
+    # fp64 autograd at the same coverage, stage by stage on the SAME fp32 fragments (an end-to-end fp64 recomputation
+    # lands a handful of fragments in the neighbouring texel cell / on the other side of a clamp, where the
+    # gradient is discontinuous; those outliers say nothing about the kernels)
+    fc = torch.from_numpy(cow["faces"]).long()
+    uv64, fuv64 = torch.from_numpy(cow["verts_uvs"]).double(), torch.from_numpy(cow["faces_uvs"]).long()
+    tt = torch.from_numpy(tex).double().requires_grad_(True)
+    vt = torch.from_numpy(cow["verts"]).double().requires_grad_(True)
+    # the fp32 depth term (zfar - z)/(zfar - znear) carries ~6e-8 of rounding which the softmax divides by gamma:
+    # with K > 1 layers the fp32 pixel can sit 6e-8/gamma away from the fp64 restatement (6e-4 at gamma = 1e-4)
+    atol = 2e-5 if K == 1 else max(2e-5, 3e-8 / gamma)
+    gtol = 5e-5 if K == 1 else max(5e-5, 2e-7 / gamma)
+    for b in range(B):
+        p2f = frag[0][b].cpu().long()
+        mask = p2f >= 0
+        bl, zl, dl = (frag[i][b].cpu().double().requires_grad_(True) for i in (2, 1, 3))
+        colors = SR.sample_texture(bl, p2f, uv64, fuv64, tt)
+        r, a_ = SR.softmax_rgb_blend(colors, zl, dl, mask, sigma, gamma, bg)
+        np.testing.assert_allclose(rgb[b].cpu().numpy(), r.detach().permute(2, 0, 1).numpy(), atol=atol)
+        np.testing.assert_allclose(alpha[b, 0].cpu().numpy(), a_.detach().numpy(), atol=2e-5)
+        (r.permute(2, 0, 1) * torch.from_numpy(g[b]).double()).sum().backward()
+        # d/d depth and d/d distance multiply (colour_k - pixel), an fp32 difference with ~1e-7 of rounding, by
+        # 1/(99 gamma) resp. 1/(4 sigma): that absolute floor is what is left when the true gradient vanishes (K = 1)
+        gnorm = float(np.linalg.norm(g[b]))
+        for ref_g, got_g, floor in ((bl.grad, geo[0][b], 0.0), (zl.grad, geo[1][b], 4e-7 * gnorm / (99 * gamma)),
+                                    (dl.grad, geo[2][b], 4e-7 * gnorm / (4 * sigma))):
+            m = mask.double() if ref_g.dim() == 3 else mask.double().unsqueeze(-1)
+            err = float(((got_g.cpu().double() - ref_g) * m).norm())
+            assert err <= gtol * float((ref_g * m).norm()) + floor, (err, float((ref_g * m).norm()), floor)
+        # raster + projection backward with the GPU's own upstream gradients
+        ndc_b = SR.project(vt, torch.from_numpy(R[b]).double(), torch.from_numpy(T[b]).double())
+        # (the fp32 ndc the kernels consumed, with the fp64 projection's graph attached)
+        ndc_b = ndc_b + (ndc[b].cpu().double() - ndc_b).detach()
+        bary64, pz64, sd64, m64 = SR.soft_geometry(ndc_b, fc, p2f, S, clip)
+        md = m64.double()
+        ((bary64 * geo[0][b].cpu().double() * md.unsqueeze(-1)).sum() + (pz64 * geo[1][b].cpu().double() * md).sum()
+         + (sd64 * geo[2][b].cpu().double() * md).sum()).backward()
+    rel_t = float((gt.cpu().double() - tt.grad).norm() / tt.grad.norm())
+    rel_v = float((gverts.cpu().double() - vt.grad).norm() / vt.grad.norm())
+    assert rel_t <= (2e-5 if K == 1 else max(2e-5, 2e-7 / gamma)), rel_t
+    assert rel_v <= 5e-5, rel_v

@@ -152,3 +152,20 @@ def test_api_only_losses_match_the_oracle(golden_dir):
                 return (cur * 3 - 1).permute(0, 2, 3, 1)
     assert abs(float(L.rgb_range_loss(M)) - float(d["rgb_range"])) <= 1e-2
     assert abs(float(P.tv_loss_ref(cur, masks)) - float(L.compute_tv_loss(cur, masks))) <= 1e-7
+
+
+def test_raster_settings_and_blend_params_validation():
+    """PyTorch3D defaults: clip_barycentric_coords follows blur_radius > 0; unsupported switches fail loudly."""
+    from st3d.render import BlendParams, RasterizationSettings, uses_hard_path
+    rs = RasterizationSettings(image_size=512, blur_radius=0.0, faces_per_pixel=1)       # first_approach.py:107
+    assert rs.is_hard and not rs.clip_barycentric_coords and uses_hard_path(rs, None) and uses_hard_path(rs, BlendParams())
+    soft = RasterizationSettings(image_size=(64, 64), blur_radius=1e-4, faces_per_pixel=8, bin_size=0)
+    assert soft.image_size == 64 and soft.clip_barycentric_coords and not soft.is_hard
+    assert not RasterizationSettings(blur_radius=1e-4, clip_barycentric_coords=False).clip_barycentric_coords
+    assert not uses_hard_path(rs, BlendParams(sigma=1e-3)) and not uses_hard_path(rs, BlendParams(background_color=(0, 0, 0)))
+    for bad in (dict(faces_per_pixel=0), dict(faces_per_pixel=9), dict(blur_radius=-1.0), dict(cull_backfaces=True),
+                dict(perspective_correct=False), dict(image_size=(64, 32))):
+        with pytest.raises((NotImplementedError, ValueError)):
+            RasterizationSettings(**bad)
+    with pytest.raises(ValueError):
+        BlendParams(gamma=0.0)

@@ -1,0 +1,65 @@
+"""The general soft-rasteriser restatement (oracle/raster_ref.c: ref_rasterize_k, oracle/soft_ref.py).
+PARITY UNPINNED w.r.t. PyTorch3D (absent): hand-computable cases + consistency with the K=1 path.  CPU only."""
+import numpy as np
+import torch
+
+from oracle import render_ref as rr
+from oracle import soft_ref as SR
+
+
+def test_k1_blur0_equals_the_hard_rasteriser(cow):
+    R, T = rr.look_at_view_transform(2.10, [15.0], [40.0], at=(0, 0.10, 0.25))
+    ndc = rr.project_verts(cow["verts"], R[0], T[0])
+    a = rr.rasterize(ndc, cow["faces"], 48, 0.0, 4)
+    b = rr.rasterize_k(ndc, cow["faces"], 48, 1, 0.0, clip_bary=False, nthreads=4)
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y[..., 0] if y.ndim == 3 else y[..., 0, :])
+
+
+def test_k_faces_are_depth_sorted_and_blur_adds_a_halo():
+    S = 16
+    tri = [[-0.5, -0.5], [0.5, -0.5], [0.0, 0.5]]
+    v = np.array([t + [3.0] for t in tri] + [t + [1.0] for t in tri] + [t + [2.0] for t in tri], np.float32)
+    f = np.array([[0, 1, 2], [3, 4, 5], [6, 7, 8]], np.int32)
+    p2f, zbuf, bary, dists = rr.rasterize_k(v, f, S, 2, 0.0)
+    cov = p2f[..., 0] >= 0
+    assert cov.sum() > 10
+    assert np.all(p2f[cov][:, 0] == 1) and np.all(p2f[cov][:, 1] == 2)          # two nearest of three, ascending z
+    assert np.allclose(zbuf[cov], [1.0, 2.0])
+    p2f3, *_ = rr.rasterize_k(v, f, S, 4, 0.0)
+    assert np.all(p2f3[cov][:, :3] == [1, 2, 0]) and np.all(p2f3[cov][:, 3] == -1)
+    # blur: pixels just outside the triangle are kept with a positive distance < blur_radius
+    blur = 0.02
+    p2fb, zb, bb, db = rr.rasterize_k(v[3:6], np.array([[0, 1, 2]], np.int32), S, 1, blur)
+    halo = (p2fb[..., 0] >= 0) & ~cov
+    assert halo.sum() > 0 and np.all(db[..., 0][halo] > 0) and np.all(db[..., 0][halo] < blur)
+    assert np.all(db[..., 0][cov] < 0)
+    # clipped barycentrics are in [0,1] and sum to 1 on halo pixels
+    assert np.all(bb[..., 0, :][halo] >= 0) and np.allclose(bb[..., 0, :][halo].sum(-1), 1.0, atol=1e-6)
+
+
+def test_soft_blend_reduces_to_the_k1_formula(cow):
+    """softmax_rgb_blend with K = 1 equals the (prob*texel + 1e-10)/(prob + 1e-10) of the hard path."""
+    S, Tn = 40, 16
+    R, T = rr.look_at_view_transform(2.10, [10.0], [25.0], at=(0, 0.10, 0.25))
+    tex = np.random.default_rng(0).random((Tn, Tn, 3), dtype=np.float32)
+    imgs, masks, frags = rr.render_views(cow["verts"], cow["faces"], cow["verts_uvs"], cow["faces_uvs"], tex, R, T, S, 4)
+    p2f = torch.from_numpy(frags[0][0]).long()[..., None]
+    rgb, alpha = SR.soft_render(torch.from_numpy(cow["verts"]), torch.from_numpy(R[0]), torch.from_numpy(T[0]),
+                                torch.from_numpy(cow["faces"]).long(), p2f, torch.from_numpy(cow["verts_uvs"]),
+                                torch.from_numpy(cow["faces_uvs"]).long(), torch.from_numpy(tex), S, False, 1e-4, 1e-4)
+    np.testing.assert_allclose(rgb.numpy(), imgs[0], atol=3e-5)
+    np.testing.assert_array_equal((alpha > 0).float().numpy(), masks[0][0])
+
+
+def test_blend_weights_two_layers():
+    """Two layers at equal depth and equal edge distance blend 50/50; gamma -> small makes the nearer one win."""
+    colors = torch.tensor([[[[1.0, 0, 0], [0, 0, 1.0]]]])                       # (1,1,K=2,3)
+    z = torch.tensor([[[2.0, 2.0]]])
+    d = torch.tensor([[[-0.01, -0.01]]])
+    m = torch.ones(1, 1, 2, dtype=torch.bool)
+    rgb, a = SR.softmax_rgb_blend(colors, z, d, m, sigma=1e-2, gamma=1e-2)
+    assert abs(float(rgb[0, 0, 0]) - float(rgb[0, 0, 2])) < 1e-6 and float(a) > 0.9
+    z2 = torch.tensor([[[1.0, 2.0]]])
+    rgb2, _ = SR.softmax_rgb_blend(colors, z2, d, m, sigma=1e-2, gamma=1e-4)
+    assert float(rgb2[0, 0, 0]) > 0.99 and float(rgb2[0, 0, 2]) < 0.01
