@@ -147,8 +147,8 @@ struct st3d_plan {
     struct Ev { int fam; hipEvent_t a, b; };
     std::vector<Ev> evs;
     std::vector<hipEvent_t> pool;
-    float fam_ms[6];
-    int fam_n[6];
+    float fam_ms[ST3D_PROFILE_FAMILIES];
+    int fam_n[ST3D_PROFILE_FAMILIES];
 };
 
 namespace {
@@ -183,7 +183,8 @@ struct Scope {   // HIP-event bracket around one kernel family (only when profil
     }
 };
 
-enum { F_CONV_FWD = 0, F_CONV_DGRAD = 1, F_POOL = 2, F_GRAM_FWD = 3, F_GRAM_BWD = 4, F_ELEM = 5 };
+// F_CONV_*: the Winograd launches; F_CONVX_*: the convs Winograd does not cover (conv1_1, odd shapes, ST3D_CONV=direct)
+enum { F_CONV_FWD = 0, F_CONV_DGRAD = 1, F_POOL = 2, F_GRAM_FWD = 3, F_GRAM_BWD = 4, F_ELEM = 5, F_CONVX_FWD = 6, F_CONVX_DGRAD = 7 };
 
 __global__ void combine_loss_kernel(float *loss, float sw, float cw) { loss[0] = cw * loss[1] + sw * loss[2]; }
 
@@ -199,8 +200,8 @@ int forward(st3d_plan *p, const float *imgs, int n, int upto, bool keep_full, hi
                 st3d::set_error("st3d_plan_forward: weights of module %d were never set", m);
                 return ST3D_E_STATE;
             }
-            Scope sc(p, F_CONV_FWD, s);
             const bool wino = p->vgg->use_wino && p->vgg->uf[cs] && st3d_wino_supported(Cin, kConvCout[cs], H, W);
+            Scope sc(p, wino ? F_CONV_FWD : F_CONVX_FWD, s);
             if (wino) {
                 const int pool_m = m + 2;          // conv, relu, pool
                 const int pps = (pool_m <= upto) ? pool_slot(pool_m) : -1;
@@ -412,8 +413,8 @@ extern "C" int st3d_plan_loss(st3d_plan *p, const float *current, int n, int bat
         if (!have_g) continue;
         float *dst = (cs == 0) ? grad_current : gn;
         {
-            Scope sc(p, F_CONV_DGRAD, s);
             const bool wino = p->vgg->use_wino && p->vgg->ud[cs] && st3d_wino_supported(kConvCout[cs], kConvCin[cs], H, W);
+            Scope sc(p, wino ? F_CONV_DGRAD : F_CONVX_DGRAD, s);
             if (g_is_pooled) {
                 if (wino)
                     ST3D_TRY(st3d_wino_dgrad_unpool(g, p->pidx[pool_of_g], p->act[kPoolIdx[pool_of_g]], p->vgg->ud[cs], dst, n,
@@ -455,7 +456,7 @@ extern "C" int st3d_plan_profile_read(st3d_plan *p, float *ms_out, int *launches
         p->pool.push_back(e.b);
     }
     p->evs.clear();
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < ST3D_PROFILE_FAMILIES; ++i) {
         if (ms_out) ms_out[i] = p->fam_ms[i];
         if (launches_out) launches_out[i] = p->fam_n[i];
         p->fam_ms[i] = 0.f;

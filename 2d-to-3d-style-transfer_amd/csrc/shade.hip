@@ -120,16 +120,15 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(const float *__restrict_
     const size_t o10 = ((size_t)q.r1 * T + q.x0) * 3, o11 = ((size_t)q.r1 * T + q.x1) * 3;
     const float *g = grad_rgb + b * 3 * HW + p;
     float gix = 0.f, giy = 0.f;
+    const float gk[3] = {g[0] * k, g[HW] * k, g[2 * HW] * k};
+    if (want_uv) {      // texel reads before any atomic: on gfx9 a load queued behind atomics returns after them
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float gc = g[c * HW] * k;
-        float t00 = 0.f, t01 = 0.f, t10 = 0.f, t11 = 0.f;
-        if (q.vy0 && q.vx0) { if (gtex) atomicAdd(gtex + o00 + c, gc * w00); if (want_uv) t00 = tex[o00 + c]; }
-        if (q.vy0 && q.vx1) { if (gtex) atomicAdd(gtex + o01 + c, gc * w01); if (want_uv) t01 = tex[o01 + c]; }
-        if (q.vy1 && q.vx0) { if (gtex) atomicAdd(gtex + o10 + c, gc * w10); if (want_uv) t10 = tex[o10 + c]; }
-        if (q.vy1 && q.vx1) { if (gtex) atomicAdd(gtex + o11 + c, gc * w11); if (want_uv) t11 = tex[o11 + c]; }
-        gix += gc * ((t01 - t00) * q.wy0 + (t11 - t10) * q.wy1);
-        giy += gc * ((t10 - t00) * q.wx0 + (t11 - t01) * q.wx1);
+        for (int c = 0; c < 3; ++c) {
+            const float t00 = (q.vy0 && q.vx0) ? tex[o00 + c] : 0.f, t01 = (q.vy0 && q.vx1) ? tex[o01 + c] : 0.f;
+            const float t10 = (q.vy1 && q.vx0) ? tex[o10 + c] : 0.f, t11 = (q.vy1 && q.vx1) ? tex[o11 + c] : 0.f;
+            gix += gk[c] * ((t01 - t00) * q.wy0 + (t11 - t10) * q.wy1);
+            giy += gk[c] * ((t10 - t00) * q.wx0 + (t11 - t01) * q.wx1);
+        }
     }
     const float gu = q.cx ? 0.f : gix * (float)(T - 1);
     const float gv = q.cy ? 0.f : giy * (float)(T - 1);
@@ -138,6 +137,15 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(const float *__restrict_
         gbary[3 * i] = gu * uvs[2 * u0] + gv * uvs[2 * u0 + 1];
         gbary[3 * i + 1] = gu * uvs[2 * u1] + gv * uvs[2 * u1 + 1];
         gbary[3 * i + 2] = gu * uvs[2 * u2] + gv * uvs[2 * u2 + 1];
+    }
+    if (gtex) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (q.vy0 && q.vx0) atomicAdd(gtex + o00 + c, gk[c] * w00);
+            if (q.vy0 && q.vx1) atomicAdd(gtex + o01 + c, gk[c] * w01);
+            if (q.vy1 && q.vx0) atomicAdd(gtex + o10 + c, gk[c] * w10);
+            if (q.vy1 && q.vx1) atomicAdd(gtex + o11 + c, gk[c] * w11);
+        }
     }
 }
 

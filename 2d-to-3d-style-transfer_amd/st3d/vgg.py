@@ -203,10 +203,10 @@ class PerceptualPlan:
         call("st3d_plan_profile", self._h, 1 if enable else 0)
 
     def profile_read(self):
-        ms = (ctypes.c_float * 6)()
-        nl = (ctypes.c_int * 6)()
+        ms = (ctypes.c_float * 8)()
+        nl = (ctypes.c_int * 8)()
         call("st3d_plan_profile_read", self._h, ms, nl)
-        names = ("conv_fwd", "conv_dgrad", "pool", "gram_fwd", "gram_bwd", "elementwise")
+        names = ("conv_fwd", "conv_dgrad", "pool", "gram_fwd", "gram_bwd", "elementwise", "convx_fwd", "convx_dgrad")
         return {k: {"ms": ms[i], "launches": nl[i]} for i, k in enumerate(names)}
 
 

@@ -15,8 +15,9 @@ region (`--no-hoist` recomputes them every step like the reference does).  Scali
 every rank renders 8 views of the SAME texture, so the job does N*8 views per step;
 `value` counts 8-view iterations per second over the whole job (= steps/s * N).
 
-Prints ONE JSON line (rank 0).  `roofline` prices the whole step against the fp32-MFMA peak with
-the algorithmic flop count of SURVEY.md 8d (396.9 GFLOP per 512^2 view-step, targets hoisted);
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (the Winograd conv launches, ~83 % of
+the step) against the fp32-MFMA peak from HIP events on the launch stream; `step_roofline` prices the whole
+step with the algorithmic flop count of SURVEY.md 8d (396.9 GFLOP per 512^2 view-step, targets hoisted);
 `cpu_baseline` times the CPU restatement (oracle/) of the reference's step on the host cores on a
 bounded sample (1 view) and scales it to the 8-view step.
 """
@@ -120,6 +121,8 @@ def main():
     ap.add_argument("--no-hoist", action="store_true", help="recompute content renders + VGG targets every step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-kernels", action="store_true", help="extra untimed steps with per-kernel-family HIP events")
+    ap.add_argument("--target", choices=["texture", "mesh", "both"], default="texture",
+                    help="optimization_target (BASELINE configs[1] = texture; configs[4] = both)")
     args = ap.parse_args()
 
     from st3d import optim as st3d_optim
@@ -150,8 +153,10 @@ def main():
     gen = torch.Generator().manual_seed(0)                  # fixed cameras: every run renders the same views
     cameras = U.build_random_cameras(global_views, generator=gen)
     my_cams = cameras[rank * Bv:(rank + 1) * Bv]
-    out = U.setup_optimizations("texture", content_mesh, 0.01)
+    out = U.setup_optimizations(args.target, content_mesh, 0.01)
     optimizer, texture_map = out["optimizer"], out["texture_map"]
+    reg_weights = {"main_loss_weight": 3.0, "mesh_verts_weight": 1.0, "mesh_edge_loss_weight": 1.0,
+                   "mesh_laplacian_smoothing_weight": 1.0, "mesh_normal_consistency_weight": 1.0}   # second_approach.py:33-37
     style_tensors = style_image.expand(Bv, -1, -1, -1)
 
     def content_targets():
@@ -167,8 +172,8 @@ def main():
         mesh = U.build_mesh(out["verts_uvs"], out["faces_uvs"], texture_map, out["verts"], out["faces"])
         cur, masks = U.render_meshes(renderer, mesh, my_cams)
         cur = U.apply_background(cur, masks, background_type="white", background=style_tensors)
-        loss = L.compute_second_approach_loss(cur, content, style_tensors, vgg, 1e6, 1.0, out["verts"], verts, mesh, {},
-                                              "texture", batch_denom=global_views)
+        loss = L.compute_second_approach_loss(cur, content, style_tensors, vgg, 1e6, 1.0, out["verts"], verts, mesh,
+                                              reg_weights, args.target, batch_denom=global_views)
         loss.backward()
         optimizer.step()
         return loss
@@ -200,42 +205,80 @@ def main():
         final_loss = float(lt[0])
 
     kernels = None
+    nprof = 5
     if args.profile_kernels or world == 1:
+        # per-kernel-family HIP events (recorded by libst3d on the stream the kernels are launched on) over nprof
+        # further steps of the same loop, right after the timed region
         plan = vgg.plan(Bv, S)
         plan.profile(True)
-        nprof = 3
         for _ in range(nprof):
             step()
         torch.cuda.synchronize()
         pr = plan.profile_read()
         plan.profile(False)
         s2 = (S / 512.0) ** 2
-        flops = {"conv_fwd": 189.35e9 * s2 * Bv, "conv_dgrad": 189.35e9 * s2 * Bv, "gram_fwd": 9.13e9 * s2 * Bv,
-                 "gram_bwd": 9.13e9 * s2 * Bv}
+        wino = os.environ.get("ST3D_CONV") != "direct"
+        f_conv = (189.35e9 - 0.906e9 if wino else 189.35e9) * s2 * Bv
+        flops = {"conv_fwd": f_conv, "conv_dgrad": f_conv, "convx_fwd": 0.906e9 * s2 * Bv if wino else 0.0,
+                 "convx_dgrad": 0.906e9 * s2 * Bv if wino else 0.0, "gram_fwd": 9.13e9 * s2 * Bv, "gram_bwd": 9.13e9 * s2 * Bv}
         kernels = {}
         for k, v in pr.items():
             ms = v["ms"] / nprof
             kernels[k] = {"ms_per_step": round(ms, 4), "launches_per_step": v["launches"] // nprof}
-            if k in flops and ms > 0:
-                kernels[k]["tflops"] = round(flops[k] / (ms * 1e-3) / 1e12, 2)
-                kernels[k]["frac_of_peak"] = round(flops[k] / (ms * 1e-3) / PEAK_FP32_MFMA, 4)
+            if flops.get(k) and ms > 0:
+                kernels[k]["alg_tflops"] = round(flops[k] / (ms * 1e-3) / 1e12, 2)
+                kernels[k]["alg_frac_of_peak"] = round(flops[k] / (ms * 1e-3) / PEAK_FP32_MFMA, 4)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         s2 = (S / 512.0) ** 2
+        wino = os.environ.get("ST3D_CONV") != "direct"
         f_alg_step = F_ALG_VIEW_512 * s2 * Bv + (0 if not args.no_hoist else 145.86e9 * s2 * Bv)
-        achieved = f_alg_step / (dev_ms / args.steps * 1e-3)
-        f_exec_step = F_EXEC_VIEW_512 * s2 * Bv if os.environ.get("ST3D_CONV") != "direct" else f_alg_step
-        executed = f_exec_step / (dev_ms / args.steps * 1e-3)
-        traffic, traffic_src = None, None
+        f_exec_step = F_EXEC_VIEW_512 * s2 * Bv if wino else f_alg_step
+        step_s = dev_ms / args.steps * 1e-3
+        std_cfg = S == 512 and Bv == 8 and not args.no_hoist and wino
+        traffic = {}
         tpath = os.path.join(ROOT, "profiles", "r01_c_pmc_traffic.json")
-        if os.path.exists(tpath) and S == 512 and Bv == 8 and not args.no_hoist:
+        if os.path.exists(tpath) and std_cfg:
             with open(tpath) as fh:
-                tj = json.load(fh)
-            traffic = tj["fetch_bytes_raw_per_step"] + tj["write_bytes_per_step"]
-            traffic_src = ("HBM bytes per step (whole step = the priced unit) from committed PMC passes, not measured live: "
-                           "profiles/r01_c_pmc_traffic.json; FETCH_SIZE raw (gfx950 under-reports 16-B/lane streams by up to 2x) "
-                           "+ WRITE_SIZE")
+                traffic = json.load(fh)
+        step_roofline = {
+            "bound": "mfma", "achieved": round(f_alg_step / step_s / 1e12, 3), "peak": PEAK_FP32_MFMA / 1e12, "unit": "TFLOP/s",
+            "frac": round(f_alg_step / step_s / PEAK_FP32_MFMA, 4),
+            "executed": round(f_exec_step / step_s / 1e12, 3), "executed_frac": round(f_exec_step / step_s / PEAK_FP32_MFMA, 4),
+            "traffic": (traffic["fetch_bytes_raw_per_step"] + traffic["write_bytes_per_step"]) if traffic else None,
+            "note": "whole step per GPU (renders, losses, Adam and host gaps included): algorithmic flops of the direct "
+                    "convolutions + Grams (%.1f GF/step, SURVEY 8d) over the HIP-event time of the timed region (%.3f ms/step)"
+                    % (f_alg_step / 1e9, dev_ms / args.steps)}
+        roofline = step_roofline
+        if kernels and kernels.get("conv_fwd", {}).get("ms_per_step", 0) > 0 and kernels.get("conv_dgrad", {}).get("ms_per_step", 0) > 0:
+            # the dominant kernel: the Winograd conv launches (forward + input-gradient), priced together
+            kms = kernels["conv_fwd"]["ms_per_step"] + kernels["conv_dgrad"]["ms_per_step"]
+            kn = kernels["conv_fwd"]["launches_per_step"] + kernels["conv_dgrad"]["launches_per_step"]
+            f_conv_alg = 2 * ((189.35e9 - 0.906e9) if wino else 189.35e9) * s2 * Bv
+            f_conv_exec = f_conv_alg * (16.0 / 36.0 if wino else 1.0)
+            ktraffic = None
+            if traffic and kn == traffic.get("wino_kernel_launches_per_step"):
+                ktraffic = (traffic["wino_fetch_bytes_raw_per_step"] + traffic["wino_write_bytes_per_step"]) / kn
+            roofline = {
+                "bound": "mfma", "achieved": round(f_conv_alg / (kms * 1e-3) / 1e12, 3), "peak": PEAK_FP32_MFMA / 1e12,
+                "unit": "TFLOP/s", "frac": round(f_conv_alg / (kms * 1e-3) / PEAK_FP32_MFMA, 4),
+                "traffic": ktraffic,
+                "executed": round(f_conv_exec / (kms * 1e-3) / 1e12, 3),
+                "executed_frac": round(f_conv_exec / (kms * 1e-3) / PEAK_FP32_MFMA, 4),
+                "kernel": "wino_kernel<MODE,EPI> (csrc/wino.hip)" if wino else "conv3x3_kernel (csrc/conv.hip)",
+                "launches_per_step": kn, "avg_launch_ms": round(kms / kn, 4), "ms_per_step": round(kms, 4),
+                "share_of_step": round(kms / (dev_ms / args.steps), 4),
+                "note": "achieved = ALGORITHMIC flops of the direct 3x3 convolutions these launches replace (2*9*Cin*Cout per "
+                        "output pixel, forward + input-gradient of every VGG conv but conv1_1: %.1f GF/step = %.2f GF per "
+                        "launch on average) / their HIP-event time, measured on the launch stream over %d steps after the timed "
+                        "region.  It exceeds the fp32 MFMA peak because the kernel is Winograd F(2x2,3x3): 16 instead of 36 "
+                        "multiplies per 2x2 outputs, still fp32 products + fp32 accumulation.  executed = MFMA flops actually "
+                        "issued (16/36 of the algorithmic count) = matrix-pipe utilisation.  traffic = HBM bytes per launch "
+                        "(average) from the committed PMC passes profiles/r01_c_pmc_traffic.json (FETCH_SIZE raw + WRITE_SIZE; "
+                        "gfx950 under-reports 16-B/lane read streams by up to 2x), not re-measured live."
+                        % (f_conv_alg / 1e9, f_conv_alg / 1e9 / kn, nprof)}
+        tgt = {"texture": "texture-only optimisation", "mesh": "vertex optimisation", "both": "joint vertex + texture optimisation"}[args.target]
         res = {
             "metric": "style-transfer iters/sec (512x512, 8 views, cow_mesh)",
             "value": round(args.steps * world * (Bv / 8.0) / elapsed, 4),
@@ -244,21 +287,13 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic views (seeded cameras) of cow_mesh + Style_1 fixtures; "
                                                             "seeded He-normal VGG-19 weights (pretrained weights need a download)",
-            "config": {"workload": "BASELINE.json configs[1]: cow_mesh + Style_1, %dx%d, %d views/GPU/iter, texture-only "
-                                   "optimisation (second_approach loop body)" % (S, S, Bv),
+            "config": {"workload": "BASELINE.json configs[1]: cow_mesh + Style_1, %dx%d, %d views/GPU/iter, %s "
+                                   "(second_approach loop body)" % (S, S, Bv, tgt),
                        "global_views_per_step": global_views, "texture": "%dx%d" % (S, S),
                        "targets_hoisted": not args.no_hoist, "parallelism": "views sharded dp%d, RCCL all-reduce of the texture gradient" % world},
             "final_loss": final_loss,
-            "roofline": {"bound": "mfma", "achieved": round(achieved / 1e12, 3), "peak": PEAK_FP32_MFMA / 1e12,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": traffic,
-                         "traffic_source": traffic_src,
-                         "executed": round(executed / 1e12, 3), "executed_frac": round(executed / PEAK_FP32_MFMA, 4),
-                         "kernel": "whole step (per GPU). achieved = ALGORITHMIC flops of the direct convolutions + Grams "
-                                   "(%.1f GF/step, SURVEY 8d) over the HIP-event time (%.3f ms/step); it can exceed the fp32 "
-                                   "MFMA peak because the conv kernels are Winograd F(2x2,3x3) (16 instead of 36 multiplies "
-                                   "per 2x2 outputs, still fp32 products + fp32 accumulation). executed = MFMA flops actually "
-                                   "issued (%.1f GF/step): the matrix-pipe utilisation."
-                                   % (f_alg_step / 1e9, dev_ms / args.steps, f_exec_step / 1e9)},
+            "roofline": roofline,
+            "step_roofline": step_roofline,
         }
         if kernels:
             res["kernels"] = kernels

@@ -239,10 +239,13 @@ int st3d_plan_set_style(st3d_plan *plan, const float *style, int style_batch, in
 int st3d_plan_loss(st3d_plan *plan, const float *current, int n, int batch_denom, float style_weight,
                    float content_weight, float *loss_out, float *grad_current, st3d_stream_t stream);
 /* per-kernel-family timing of the next calls (HIP events on the call's stream): enable, then
- * read accumulated milliseconds + launch counts; families: 0 conv_fwd 1 conv_dgrad 2 pool
- * 3 gram_fwd 4 gram_bwd 5 loss/elementwise */
+ * read accumulated milliseconds + launch counts; families: 0 conv_fwd (Winograd launches) 1 conv_dgrad (Winograd)
+ * 2 pool 3 gram_fwd 4 gram_bwd 5 loss/elementwise 6 convx_fwd (convs Winograd does not cover: conv1_1, odd shapes)
+ * 7 convx_dgrad */
+#define ST3D_PROFILE_FAMILIES 8
 int st3d_plan_profile(st3d_plan *plan, int enable);
-int st3d_plan_profile_read(st3d_plan *plan, float *ms_out /*host [6]*/, int *launches_out /*host [6]*/);
+int st3d_plan_profile_read(st3d_plan *plan, float *ms_out /*host [ST3D_PROFILE_FAMILIES]*/,
+                           int *launches_out /*host [ST3D_PROFILE_FAMILIES]*/);
 
 #ifdef __cplusplus
 }
