@@ -1,217 +1,89 @@
-"""Drop-in for the reference's ``second_approach.py`` (direct 3-D optimisation): same flags and
-defaults (reference second_approach.py:22-42), same artefacts (``log.txt`` with
-``Epoch e, Loss x`` lines, ``current_images/view_k.png``, ``final_render/view_k.png``,
-``final.obj``), running on one or several MI355X.
+"""``second_approach.py`` of the reference (direct 3-D optimisation of texture / vertices under the
+perceptual loss) on MI355X: same flags, defaults and artefacts (``log.txt`` with ``Epoch e, Loss x``
+lines, ``current_images/view_k.png``, ``final_render/view_k.png``, ``final.obj``; reference
+second_approach.py:22-42, 140-202).
 
     python second_approach.py --size 512 --batch_size 8 --n_views 8 ...
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         second_approach.py --size 512 --batch_size 64 --n_views 64 ...
 
-What is hoisted out of the step relative to the reference loop (second_approach.py:145-190)
-because it does not depend on the optimised parameters: the style image load (:157), the
-content renders (:160) and, with them, the content/style VGG targets -- unless
-``--content_background noise`` draws fresh noise each step (then they are recomputed, as the
-reference does).  Multi-GPU: each rank renders its slice of the batch's views; the texture
-(and vertex) gradient is summed over ranks inside ``optimizer.step()``.
+Hoisted out of the step because it does not depend on the optimised parameters: the style image load
+(reference :157), the content renders (:160) and with them the content/style VGG targets -- unless
+``--content_background noise`` draws fresh noise every step (then they are recomputed, as the reference
+does).  With several ranks each one renders its slice of the batch's views; the gradient is summed over
+ranks inside ``optimizer.step()``.
 """
-import argparse
-import math
-import os
-
 import torch
-import torch.nn.functional as F
 from tqdm import tqdm
 
-# style transfer utilities (drop-in modules of the same names as the reference's)
+# the reference's star imports: scripts and notebooks reach everything through these three modules
 from style_transfer import *  # noqa: F401,F403
 from utils import *  # noqa: F401,F403
 from losses import *  # noqa: F401,F403
 
-from st3d import io as st3d_io
-from st3d import optim as st3d_optim
-from st3d.render import (AmbientLights, FoVPerspectiveCameras, MeshRasterizer, MeshRenderer, RasterizationSettings,
-                         SoftPhongShader)
+from st3d.cli import Flag, Run, load_scene, make_parser  # noqa: F401  (load_scene re-exported)
+
+FLAGS = [
+    Flag("epochs", int, 3000, "passes over the view set"),
+    Flag("output_path", str, "/content/output_second", "folder for log.txt, renders and the final mesh"),
+    Flag("lr", float, 0.01, "Adam step size"),
+    Flag("save_every", int, 1, "write current_images/*.png every N steps (reference: every step); 0 = never"),
+]
 
 
 def build_parser():
-    parser = argparse.ArgumentParser()
-    parser.add_argument("--n_views", default=6, type=int, help="Number of views considered by the renderer")
-    parser.add_argument("--epochs", default=3000, type=int, help="Number of epochs for style transfer")
-    parser.add_argument("--obj_path", default="./objects/cow_mesh/cow.obj", type=str, help="Path to the object")
-    parser.add_argument("--style_path", default="./imgs/Style_1.jpg", type=str, help="Path to the style image")
-    parser.add_argument("--style_weight", default=1e6, type=float, help="Weight of the style loss")
-    parser.add_argument("--content_weight", default=1.0, type=float, help="Weight of the content loss")
-    parser.add_argument("--resize_texture", default=True, type=bool, help="Whether to resize the texture to the same size of the images")
-    parser.add_argument("--size", default=768, type=int, help="Dimension of the images")
-    parser.add_argument("--output_path", default="/content/output_second", type=str, help="Output folder path")
-    parser.add_argument("--batch_size", default=4, type=int, help="Batch size")
-    parser.add_argument("--content_background", default='white', type=str, choices=['noise', 'style', 'white'], help="Type of background for the content image")
-    parser.add_argument("--current_background", default='white', type=str, choices=['noise', 'style', 'white'], help="Type of background for the current image")
-    parser.add_argument("--lr", default=0.01, type=float, help="Style Transfer Learning Rate")
-    parser.add_argument("--randomize_views", type=bool, default=True, help="Whether or not to randomize views")
-    parser.add_argument("--optimization_target", type=str, choices=['texture', 'mesh', 'both'], default="texture", help="Decide what to optimize")
-    parser.add_argument("--main_loss_weight", type=float, default=3.0, help="Weight of the main computed loss (i.e., perceptual)")
-    parser.add_argument("--mesh_edge_loss_weight", type=float, default=1.0, help="Weight of edge loss (enforces admissible weights for the edges)")
-    parser.add_argument("--mesh_laplacian_smoothing_weight", type=float, default=1.0, help="Weight of smoothing (smooth surface)")
-    parser.add_argument("--mesh_normal_consistency_weight", type=float, default=1.0, help="Weight of normal consistency")
-    parser.add_argument("--mesh_verts_weight", type=float, default=1.0, help="Mesh verts (uvs and not uvs) regularization weight")
-    # additions (defaults keep the reference behaviour)
-    parser.add_argument("--vgg_weights", default=None, type=str, help="Local VGG-19 state_dict (no download is attempted); default: ST3D_VGG19_WEIGHTS or seeded weights")
-    parser.add_argument("--seed", default=None, type=int, help="Seed the camera sampling / noise (the reference is unseeded)")
-    parser.add_argument("--save_every", default=1, type=int, help="Dump current_images PNGs every N steps (reference: every step); 0 = never")
-    return parser
-
-
-def load_scene(obj_path, size, resize_texture, device):
-    """reference second_approach.py:77-97"""
-    verts, faces, aux = st3d_io.load_obj(obj_path)
-    if aux.verts_uvs is None or faces.textures_idx is None or not aux.texture_images:
-        # e.g. objects/teapot_mesh/teapot.obj (faces `v//vn`, no mtllib): the reference crashes at
-        # first_approach.py:85-88, so there is no behaviour to match.  Per-vertex spherical UVs
-        # and a mid-grey texture with seeded noise are synthesised so BASELINE config 4 can run.
-        print(f"WARNING: {obj_path} has no UVs / texture; synthesising spherical UVs and a grey noise texture")
-        verts_uvs_cpu = st3d_io.synthesize_uvs(verts)
-        faces_uvs_cpu = faces.verts_idx.clone()
-        g = torch.Generator().manual_seed(0)
-        tex_cpu = (0.5 + 0.1 * torch.randn((size, size, 3), generator=g)).clamp(0, 1)
-    else:
-        verts_uvs_cpu, faces_uvs_cpu = aux.verts_uvs, faces.textures_idx
-        tex_cpu = list(aux.texture_images.values())[0]
-    verts = verts.to(device)
-    verts_uvs = verts_uvs_cpu[None, ...].to(device)  # (1, V, 2)
-    faces_uvs = faces_uvs_cpu[None, ...].to(device)  # (1, F, 3)
-    faces_idx = faces.verts_idx.to(device)
-    texture_image = tex_cpu[None, ...].to(device)  # (1, H, W, 3)
-    if resize_texture:
-        texture_image = F.interpolate(texture_image.permute(0, 3, 1, 2), size=size, mode='bilinear',
-                                      align_corners=False).permute(0, 2, 3, 1).contiguous()
-    return verts, faces_idx, verts_uvs, faces_uvs, texture_image
+    return make_parser(FLAGS)
 
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
-    rank, world, local = st3d_optim.init_distributed()
-    device = torch.device(f"cuda:{local}" if torch.cuda.is_available() else "cpu")
-    if device.type != "cuda":
-        raise RuntimeError("st3d needs an MI355X (libst3d has no CPU fallback)")
-    torch.cuda.set_device(device)
-    import utils as _u, style_transfer as _s, losses as _l
-    _u.device = _s.device = _l.device = device
-    if args.seed is not None:
-        torch.manual_seed(args.seed)
+    run = Run(args, lr=args.lr, image_dir="current_images")
+    reuse_content = args.content_background != 'noise'
+    content_of_batch = {}
+    steps_done = 0
 
-    loss_weights = {
-        'mesh_edge_loss_weight': args.mesh_edge_loss_weight,
-        'mesh_laplacian_smoothing_weight': args.mesh_laplacian_smoothing_weight,
-        'mesh_normal_consistency_weight': args.mesh_normal_consistency_weight,
-        'mesh_verts_weight': args.mesh_verts_weight,
-        'main_loss_weight': args.main_loss_weight,
-    }
-    output_path, size, n_views, batch_size = args.output_path, args.size, args.n_views, args.batch_size
-    if rank == 0:
-        os.makedirs(output_path, exist_ok=True)
-        os.makedirs(output_path + "/current_images", exist_ok=True)
-
-    print("Loading mesh...")
-    original_verts, original_faces, original_verts_uvs, original_faces_uvs, texture_image = load_scene(
-        args.obj_path, size, args.resize_texture, device)
-    content_mesh = build_mesh(original_verts_uvs, original_faces_uvs, texture_image, original_verts, original_faces)
-
-    cameras = FoVPerspectiveCameras(device=device)
-    raster_settings = RasterizationSettings(image_size=size, blur_radius=0.0, faces_per_pixel=1)
-    lights = AmbientLights(device=device)
-    renderer = MeshRenderer(rasterizer=MeshRasterizer(cameras=cameras, raster_settings=raster_settings),
-                            shader=SoftPhongShader(device=device, cameras=cameras, lights=lights))
-
-    print("Loading model...")
-    vgg = get_vgg(weights=args.vgg_weights)
-
-    print("Building cameras...")
-    gen = torch.Generator().manual_seed(args.seed) if args.seed is not None else None
-    cameras_list = build_random_cameras(n_views, generator=gen) if args.randomize_views else build_fixed_cameras(n_views)
-    if world > 1:       # every rank must see the same cameras
-        torch.distributed.broadcast(cameras_list.R, 0)
-        torch.distributed.broadcast(cameras_list.T, 0)
-
-    out = setup_optimizations(args.optimization_target, content_mesh, args.lr)
-    current_mesh, optimizer = out['optimizable_mesh'], out['optimizer']
-    texture_map, verts, faces = out['texture_map'], out['verts'], out['faces']
-    verts_uvs, faces_uvs = out['verts_uvs'], out['faces_uvs']
-
-    if rank == 0:
-        with open(output_path + '/log.txt', 'w') as file:
-            file.write('Logger:\n')
-
-    style_image = load_as_tensor(args.style_path, size=size)     # loop-invariant (reference reloads it per step)
-    hoist = args.content_background != 'noise'
-    content_cache = {}
-
-    print("Starting optimization...")
-    n_batches = math.ceil(n_views / batch_size)
-    step_no = 0
+    run.say("Starting optimization...")
     for epoch in range(args.epochs):
-        if rank == 0:
-            print(f"\nEpoch {epoch}")
-        total_loss = torch.zeros((), device=device)
-        for i in tqdm(range(n_batches), leave=True, desc="Batch", disable=rank != 0):
-            optimizer.zero_grad()
-            batch_start, batch_end = i * batch_size, min((i + 1) * batch_size, n_views)
-            current_batch_size = batch_end - batch_start
-            lo, hi = st3d_optim.shard_views(current_batch_size, rank, world)      # this rank's slice of the batch
-            lo, hi = batch_start + lo, batch_start + hi
-            n_local = hi - lo
-            if n_local == 0:            # more ranks than views: contribute a zero gradient
-                for p in optimizer.params:
-                    p.grad = torch.zeros_like(p)
-                optimizer.step()
+        run.say(f"\nEpoch {epoch}")
+        epoch_loss = torch.zeros((), device=run.device)
+        for vb in tqdm(list(run.batches()), leave=True, desc="Batch", disable=not run.main):
+            run.optimizer.zero_grad()
+            if vb.hi == vb.lo:                      # more ranks than views in this batch
+                run.zero_contribution()
+                run.optimizer.step()
                 continue
-            batch_cameras = cameras_list[lo:hi]
-            style_tensors = style_image.expand(n_local, -1, -1, -1)
+            cams = run.cameras[vb.lo:vb.hi]
+            style = run.style_image.expand(vb.hi - vb.lo, -1, -1, -1)
 
-            if hoist and i in content_cache:
-                content_tensors = content_cache[i]
-            else:
+            content = content_of_batch.get(vb.index) if reuse_content else None
+            if content is None:
                 with torch.no_grad():
-                    content_tensors, content_masks = render_meshes(renderer, content_mesh, batch_cameras)
-                    content_tensors = apply_background(content_tensors, content_masks, background_type=args.content_background, background=style_tensors)
-                if hoist:
-                    content_cache[i] = content_tensors
+                    img, cov = render_meshes(run.renderer, run.content_mesh, cams)
+                    content = apply_background(img, cov, background_type=args.content_background, background=style)
+                if reuse_content:
+                    content_of_batch[vb.index] = content
 
-            current_mesh = build_mesh(verts_uvs, faces_uvs, texture_map, verts, faces)
-            current_tensors, current_masks = render_meshes(renderer, current_mesh, batch_cameras)
-            current_tensors = apply_background(current_tensors, current_masks, background_type=args.current_background, background=style_tensors)
+            mesh = run.current_mesh()
+            img, cov = render_meshes(run.renderer, mesh, cams)
+            current = apply_background(img, cov, background_type=args.current_background, background=style)
 
             loss = compute_second_approach_loss(
-                current=current_tensors, content=content_tensors, style=style_tensors, model=vgg,
-                style_weight=args.style_weight, content_weight=args.content_weight, verts=verts,
-                target_verts=original_verts, mesh=current_mesh, weights=loss_weights,
-                opt_type=args.optimization_target, batch_denom=current_batch_size)
+                current=current, content=content, style=style, model=run.vgg, style_weight=args.style_weight,
+                content_weight=args.content_weight, verts=run.opt['verts'], target_verts=run.original_verts, mesh=mesh,
+                weights=run.loss_weights, opt_type=args.optimization_target, batch_denom=vb.size)
 
-            if args.save_every and step_no % args.save_every == 0:
-                for j, current_tensor in enumerate(current_tensors):
-                    tensor_to_image(current_tensor).save(output_path + f"/current_images/view_{lo + j}.png")
+            if args.save_every and steps_done % args.save_every == 0:
+                for j, view in enumerate(current):
+                    tensor_to_image(view).save(f"{run.image_dir}/view_{vb.lo + j}.png")
 
             loss.backward()
-            optimizer.step()                       # all-reduces the gradient over ranks, then fused Adam
-            total_loss += loss.detach()
-            step_no += 1
+            run.optimizer.step()                    # gradient all-reduce over ranks + fused Adam
+            epoch_loss += loss.detach()
+            steps_done += 1
 
-        if world > 1:
-            torch.distributed.all_reduce(total_loss)
-        if rank == 0:
-            with open(output_path + '/log.txt', 'a') as file:
-                file.write(f'Epoch {epoch}, Loss {total_loss.item()}\n')
+        run.log(f'Epoch {epoch}, Loss {run.global_sum(epoch_loss).item()}')
 
-    if rank == 0:
-        final_mesh = finalize_mesh(current_mesh)
-        fixed = build_fixed_cameras(12)
-        save_render(renderer, final_mesh, fixed, output_path + "/final_render")
-        tex = final_mesh.textures
-        st3d_io.save_obj(output_path + "/final.obj", final_mesh.verts_packed(), final_mesh.faces_packed(),
-                         tex.verts_uvs_padded()[0], tex.faces_uvs_padded()[0], tex.maps_padded()[0])
-    if world > 1:
-        torch.distributed.barrier()
-        torch.distributed.destroy_process_group()
+    run.export(run.current_mesh())
 
 
 if __name__ == "__main__":

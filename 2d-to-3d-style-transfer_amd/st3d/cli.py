@@ -1,0 +1,190 @@
+"""Shared scaffolding of the two command-line drivers (first_approach.py / second_approach.py).
+
+The reference repeats set-up, batching, logging and export in both scripts (first_approach.py:47-147,
+219-225; second_approach.py:44-140,196-202).  Here that is one ``Run`` object: flag tables, device /
+rank set-up, scene + renderer + VGG + cameras + optimiser, the view-batch schedule with its per-rank
+slice, the log file and the final export.  The scripts keep only their loop bodies.
+"""
+import argparse
+import math
+import os
+from collections import namedtuple
+
+import torch
+import torch.nn.functional as F
+
+from . import io as st3d_io
+from . import optim as st3d_optim
+from .render import (AmbientLights, FoVPerspectiveCameras, MeshRasterizer, MeshRenderer, RasterizationSettings,
+                     SoftPhongShader)
+
+Flag = namedtuple("Flag", "name type default help choices", defaults=(None,))
+
+_BACKGROUNDS = ['noise', 'style', 'white']
+_TARGETS = ['texture', 'mesh', 'both']
+
+# name, type, default and choices are the reference's (first_approach.py:23-45, second_approach.py:23-42); note
+# `type=bool` flags keep argparse's "any non-empty string is True" behaviour of the reference.
+SHARED_FLAGS = [
+    Flag("n_views", int, 6, "how many camera views surround the object"),
+    Flag("obj_path", str, "./objects/cow_mesh/cow.obj", "Wavefront OBJ to stylise"),
+    Flag("style_path", str, "./imgs/Style_1.jpg", "style image"),
+    Flag("style_weight", float, 1e6, "multiplier of the Gram (style) term"),
+    Flag("content_weight", float, 1.0, "multiplier of the conv4_2 (content) term"),
+    Flag("resize_texture", bool, True, "resample the texture map to size x size"),
+    Flag("size", int, 768, "side of the rendered images in pixels"),
+    Flag("batch_size", int, 4, "views per optimisation step"),
+    Flag("content_background", str, 'white', "what fills the uncovered pixels of the content renders", _BACKGROUNDS),
+    Flag("current_background", str, 'white', "what fills the uncovered pixels of the current renders", _BACKGROUNDS),
+    Flag("randomize_views", bool, True, "random cameras on a sphere instead of the fixed turntable"),
+    Flag("optimization_target", str, "texture", "which tensors Adam updates", _TARGETS),
+    Flag("main_loss_weight", float, 3.0, "weight of the image term when the mesh is optimised"),
+    Flag("mesh_edge_loss_weight", float, 1.0, "weight of the edge-length regulariser"),
+    Flag("mesh_laplacian_smoothing_weight", float, 1.0, "weight of the uniform-Laplacian regulariser"),
+    Flag("mesh_normal_consistency_weight", float, 1.0, "weight of the normal-consistency regulariser"),
+    Flag("mesh_verts_weight", float, 1.0, "weight of the distance to the original vertices"),
+    # additions; the defaults keep the reference behaviour
+    Flag("vgg_weights", str, None, "local VGG-19 state_dict (never downloaded); default ST3D_VGG19_WEIGHTS or seeded weights"),
+    Flag("seed", int, None, "seed for camera sampling / noise (the reference is unseeded)"),
+]
+
+
+def make_parser(extra_flags):
+    parser = argparse.ArgumentParser()
+    for fl in list(extra_flags) + SHARED_FLAGS:
+        kw = {"type": fl.type, "default": fl.default, "help": fl.help}
+        if fl.choices:
+            kw["choices"] = fl.choices
+        parser.add_argument("--" + fl.name, **kw)
+    return parser
+
+
+def load_scene(obj_path, size, resize_texture, device):
+    """OBJ + its texture -> (verts (V,3), faces (F,3), verts_uvs (1,VT,2), faces_uvs (1,F,3), map (1,T,T,3)) on
+    `device`, the map resampled to size x size when asked (reference second_approach.py:77-97)."""
+    verts, faces, aux = st3d_io.load_obj(obj_path)
+    if aux.verts_uvs is None or faces.textures_idx is None or not aux.texture_images:
+        # e.g. objects/teapot_mesh/teapot.obj (faces `v//vn`, no mtllib): the reference crashes at
+        # first_approach.py:85-88, so there is no behaviour to match.  Per-vertex spherical UVs
+        # and a mid-grey texture with seeded noise are synthesised so BASELINE config 4 can run.
+        print(f"WARNING: {obj_path} has no UVs / texture; synthesising spherical UVs and a grey noise texture")
+        uvs, uv_faces = st3d_io.synthesize_uvs(verts), faces.verts_idx.clone()
+        noise = torch.randn((size, size, 3), generator=torch.Generator().manual_seed(0))
+        tex = (0.5 + 0.1 * noise).clamp(0, 1)
+    else:
+        uvs, uv_faces = aux.verts_uvs, faces.textures_idx
+        tex = next(iter(aux.texture_images.values()))
+    tex = tex[None].to(device)
+    if resize_texture:
+        nchw = F.interpolate(tex.permute(0, 3, 1, 2), size=size, mode='bilinear', align_corners=False)
+        tex = nchw.permute(0, 2, 3, 1).contiguous()
+    return verts.to(device), faces.verts_idx.to(device), uvs[None].to(device), uv_faces[None].to(device), tex
+
+
+ViewBatch = namedtuple("ViewBatch", "index size lo hi")      # batch number, its global size, this rank's [lo, hi)
+
+
+class Run:
+    """Everything both drivers need before their loop starts."""
+
+    def __init__(self, args, lr, image_dir):
+        import losses as _l
+        import style_transfer as _s
+        import utils as _u
+        self.args = args
+        self.rank, self.world, local = st3d_optim.init_distributed()
+        if not torch.cuda.is_available():
+            raise RuntimeError("st3d needs an MI355X (libst3d has no CPU fallback)")
+        self.device = torch.device(f"cuda:{local}")
+        torch.cuda.set_device(self.device)
+        _u.device = _s.device = _l.device = self.device
+        if args.seed is not None:
+            torch.manual_seed(args.seed)
+        self.out_dir = args.output_path
+        self.image_dir = os.path.join(self.out_dir, image_dir)
+        if self.main:
+            os.makedirs(self.image_dir, exist_ok=True)
+        self.loss_weights = {k: getattr(args, k) for k in (
+            'mesh_edge_loss_weight', 'mesh_laplacian_smoothing_weight', 'mesh_normal_consistency_weight',
+            'mesh_verts_weight', 'main_loss_weight')}
+
+        self.say("Loading mesh...")
+        verts, faces, verts_uvs, faces_uvs, tex = load_scene(args.obj_path, args.size, args.resize_texture, self.device)
+        self.original_verts = verts
+        self.content_mesh = _u.build_mesh(verts_uvs, faces_uvs, tex, verts, faces)
+
+        cams = FoVPerspectiveCameras(device=self.device)
+        settings = RasterizationSettings(image_size=args.size, blur_radius=0.0, faces_per_pixel=1)
+        self.renderer = MeshRenderer(rasterizer=MeshRasterizer(cameras=cams, raster_settings=settings),
+                                     shader=SoftPhongShader(device=self.device, cameras=cams,
+                                                            lights=AmbientLights(device=self.device)))
+        self.say("Loading model...")
+        self.vgg = _u.get_vgg(weights=args.vgg_weights)
+
+        self.say("Building cameras...")
+        gen = torch.Generator().manual_seed(args.seed) if args.seed is not None else None
+        self.cameras = (_u.build_random_cameras(args.n_views, generator=gen) if args.randomize_views
+                        else _u.build_fixed_cameras(args.n_views))
+        if self.world > 1:                      # every rank must look through the same cameras
+            torch.distributed.broadcast(self.cameras.R, 0)
+            torch.distributed.broadcast(self.cameras.T, 0)
+
+        # one optimiser (one Adam state) for the whole run, over all view batches
+        self.opt = _u.setup_optimizations(args.optimization_target, self.content_mesh, lr)
+        self.optimizer = self.opt['optimizer']
+        self.style_image = _u.load_as_tensor(args.style_path, size=args.size)   # loop-invariant; the reference reloads it
+        self._log = os.path.join(self.out_dir, 'log.txt')
+        if self.main:
+            with open(self._log, 'w') as fh:
+                fh.write('Logger:\n')
+        self._utils = _u
+
+    # ---- small helpers
+    @property
+    def main(self):
+        return self.rank == 0
+
+    def say(self, msg):
+        if self.main:
+            print(msg)
+
+    def log(self, line):
+        if self.main:
+            with open(self._log, 'a') as fh:
+                fh.write(line + '\n')
+
+    def current_mesh(self):
+        o = self.opt
+        return self._utils.build_mesh(o['verts_uvs'], o['faces_uvs'], o['texture_map'], o['verts'], o['faces'])
+
+    def batches(self):
+        """The reference's schedule (ceil(n_views / batch_size) consecutive slices) with this rank's share of each."""
+        n, bs = self.args.n_views, self.args.batch_size
+        for i in range(math.ceil(n / bs)):
+            first, size = i * bs, min((i + 1) * bs, n) - i * bs
+            lo, hi = st3d_optim.shard_views(size, self.rank, self.world)
+            yield ViewBatch(i, size, first + lo, first + hi)
+
+    def zero_contribution(self):
+        """A rank without views in this batch still joins the gradient all-reduce (with zeros)."""
+        for p in self.optimizer.params:
+            p.grad = torch.zeros_like(p)
+
+    def global_sum(self, value):
+        t = value.detach().clone()
+        if self.world > 1:
+            torch.distributed.all_reduce(t)
+        return t
+
+    def export(self, mesh):
+        """final_render/view_k.png from 12 turntable cameras + final.obj/.mtl/.png (first_approach.py:219-225)."""
+        if self.main:
+            u = self._utils
+            final = u.finalize_mesh(mesh)
+            u.save_render(self.renderer, final, u.build_fixed_cameras(12), os.path.join(self.out_dir, "final_render"))
+            tex = final.textures
+            st3d_io.save_obj(os.path.join(self.out_dir, "final.obj"), final.verts_packed(), final.faces_packed(),
+                             tex.verts_uvs_padded()[0], tex.faces_uvs_padded()[0], tex.maps_padded()[0])
+        if self.world > 1:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()

@@ -1,13 +1,13 @@
-"""Drop-in for the reference's ``utils.py`` (same function names, arguments and return layouts:
-reference utils.py:19-210) on libst3d -- no torchvision, no PyTorch3D.
+"""Host helpers with the reference's ``utils.py`` surface (names, arguments, return layouts of
+reference utils.py:19-210) implemented on libst3d -- no torchvision, no PyTorch3D.
 
-Differences that are NOT visible in results:
-  * ``render_meshes`` renders all cameras of the batch in one set of launches instead of one
-    renderer call per camera (reference :68-69) and gets NCHW RGB + mask straight from the
-    shade kernel instead of permuting an RGBA image (reference :70-76);
-  * ``get_vgg`` never downloads: local state_dict via ST3D_VGG19_WEIGHTS, else seeded weights;
-  * ``setup_optimizations`` hands back the fused HIP Adam (st3d.optim.Adam), which also sums the
-    gradient over ranks when the view batch is sharded across GPUs.
+What differs from the reference, none of it visible in results:
+  * ``render_meshes`` submits every camera of the batch in one set of launches (the reference calls the
+    renderer once per camera, :68-69) and takes NCHW colour + coverage straight from the shade kernel
+    instead of slicing and permuting an RGBA image (:70-76);
+  * ``get_vgg`` never downloads: a local state_dict (argument or ST3D_VGG19_WEIGHTS) or seeded weights;
+  * ``setup_optimizations`` returns the fused HIP Adam (st3d.optim.Adam), which also sums the gradient
+    over ranks when the view batch is sharded across GPUs.
 """
 import os
 import random
@@ -21,158 +21,136 @@ from st3d import optim as _st3d_optim
 from st3d import render as _render
 from st3d import vgg as _vgg
 from st3d.render import FoVPerspectiveCameras, Meshes, RotateAxisAngle, TexturesUV, look_at_view_transform  # noqa: F401
-from style_transfer import *  # noqa: F401,F403  (the reference does the same, utils.py:12)
+from style_transfer import *  # noqa: F401,F403  (star re-export relied on by the CLIs, reference utils.py:12)
 
-# Check if CUDA is available
 device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
 
 
-class _BackgroundFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, tensors, masks, backgrounds):
-        ctx.masks = masks
-        return _ops.apply_background(tensors.detach(), masks, backgrounds)
+# ------------------------------------------------------------------------------------------ compositing
+class _Composite(torch.autograd.Function):
+    """out = img * mask + bg * (1 - mask) in one launch; d out / d img = mask."""
 
     @staticmethod
-    def backward(ctx, g):
-        return _ops.apply_background(g.contiguous(), ctx.masks, None), None, None
+    def forward(ctx, img, mask, bg):
+        ctx.mask = mask
+        return _ops.apply_background(img.detach(), mask, bg)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return _ops.apply_background(grad_out.contiguous(), ctx.mask, None), None, None
 
 
-# Helper function to blend image with background
-def apply_background(tensors, masks, background_type = 'noise', background = None):
-
-    if background_type == 'noise':
-        backgrounds = torch.rand(tensors.shape, device = tensors.device)
-        return _BackgroundFn.apply(tensors, masks, backgrounds)
-
-    elif background_type == 'style':
-        return _BackgroundFn.apply(tensors, masks, background)
-
-    elif background_type == 'white':
+def apply_background(tensors, masks, background_type='noise', background=None):
+    """reference :19-30 -- 'white' is the identity because the renderer's own background is white;
+    'noise' draws a fresh U[0,1) image per call; any other type returns None like the reference."""
+    if background_type == 'white':
         return tensors
+    if background_type == 'style':
+        return _Composite.apply(tensors, masks, background)
+    if background_type == 'noise':
+        return _Composite.apply(tensors, masks, torch.rand(tensors.shape, device=tensors.device))
+    return None
 
 
-# Load and preprocess the images
+# ------------------------------------------------------------------------------------------ images
 def load_as_tensor(image_path, size=512):
-    """PIL RGB -> bilinear (antialiased) resize to (size,size) -> float32 CHW /255, what
-    transforms.Resize + ToTensor do to a PIL image (reference :34-44)."""
-    image = Image.open(image_path).convert('RGB').resize((size, size), Image.BILINEAR)
-    arr = np.asarray(image, dtype=np.uint8)
-    tensor = torch.from_numpy(arr.copy()).permute(2, 0, 1).to(torch.float32).div(255.0)
-    return tensor[:3, :, :].contiguous().to(device)
+    """File -> (3,size,size) float32 in [0,1] on `device`: RGB decode, PIL's antialiased bilinear
+    resize, /255 -- what transforms.Resize((size,size)) + ToTensor() give for a PIL image (:34-44)."""
+    with Image.open(image_path) as im:
+        rgb = im.convert('RGB').resize((size, size), Image.BILINEAR)
+    hwc = torch.from_numpy(np.array(rgb, dtype=np.uint8))
+    return (hwc.permute(2, 0, 1).float() / 255.0).contiguous().to(device)
 
 
-# Load the VGG19 feature extractor (frozen)
+def tensor_to_image(tensor):
+    """(1,3,H,W) or (3,H,W) -> PIL image; values clamped to [0,1], scaled by 255 and truncated
+    (ToPILImage semantics, :56-61)."""
+    chw = tensor.detach().reshape(tensor.shape[-3:]).clamp(0, 1).cpu()
+    return Image.fromarray((chw * 255).to(torch.uint8).permute(1, 2, 0).numpy())
+
+
 def get_vgg(weights=None, seed=0):
+    """Frozen VGG-19 feature stack (:48-52) as an st3d.vgg.Vgg19Features."""
     return _vgg.get_vgg(weights=weights, device=device, seed=seed)
 
 
-# Convert tensor to image for display
-def tensor_to_image(tensor):
-    image = tensor.clone().detach()
-    image = image.squeeze(0)  # Remove batch dimension
-    image = image.clamp(0, 1).cpu()
-    # ToPILImage on a float tensor: mul(255) then truncating byte cast
-    arr = image.mul(255).to(torch.uint8).permute(1, 2, 0).numpy()
-    return Image.fromarray(arr)
-
-
-# Render the content tensor
+# ------------------------------------------------------------------------------------------ rendering
 def render_meshes(renderer, meshes, cameras):
-    tensors, coverage = renderer.render(meshes, cameras)
-    if not renderer.is_hard:
-        coverage = (coverage.detach() > 0).float()      # soft settings: alpha -> mask (reference :72)
-    return tensors, coverage      # (BATCH, 3, H, W), (BATCH, 1, H, W) with mask = alpha > 0
+    """-> colour (n,3,H,W), mask (n,1,H,W) with mask = (alpha > 0) as float (:65-77)."""
+    colour, coverage = renderer.render(meshes, cameras)
+    if not renderer.is_hard:                 # soft settings hand back alpha itself
+        coverage = (coverage.detach() > 0).float()
+    return colour, coverage
 
 
-# Save final optimized images
 def save_render(renderer, meshes, cameras, path):
-
+    """view_<k>.png for every camera (:81-91)."""
     os.makedirs(path, exist_ok=True)
-
-    # Render optimized mesh
-    tensors, _ = render_meshes(renderer, meshes, cameras)
-
-    for i in range(tensors.shape[0]):
-        tensor_to_image(tensors[i, ...]).save(f"{path}/view_{i}.png")
-
-
-def finalize_mesh(mesh):
-    textures = mesh.textures
-    # colours clamped to (0,1); geometry and UVs as they are
-    final_textures = TexturesUV(verts_uvs=textures.verts_uvs_padded(), faces_uvs=textures.faces_uvs_padded(),
-                                maps=finalize_tensor(textures.maps_padded()))
-    return Meshes(verts=mesh.verts_padded(), faces=mesh.faces_padded(), textures=final_textures)
+    colour, _ = render_meshes(renderer, meshes, cameras)
+    for k, img in enumerate(colour):
+        tensor_to_image(img).save(os.path.join(path, f"view_{k}.png"))
 
 
 def finalize_tensor(tensor):
-    final_tensor = torch.clamp(tensor, 0.0, 1.0).detach()
-    return final_tensor
+    return tensor.detach().clamp(0.0, 1.0)
 
 
-def build_fixed_cameras(n_views, dist=3.0, shuffle = True):
-
-    # viewpoints: half rotate about X, half about Y (reference :124-128)
-    x_views = (n_views // 2)
-    y_views = n_views - x_views
-    angles = [(a.item(), "X") for a in torch.linspace(0, 315, x_views)] + \
-             [(a.item(), "Y") for a in torch.linspace(45, 315, y_views)]
-
-    if shuffle:
-        random.shuffle(angles)
-
-    R_list = torch.stack([RotateAxisAngle(angle, axis=axis).get_matrix()[..., :3, :3].squeeze(0) for angle, axis in angles], dim=0)
-    T_list = torch.tensor([[0.0, 0.0, dist]]).repeat(len(angles), 1)
-
-    return FoVPerspectiveCameras(R=R_list, T=T_list, device=device)
-
-
-def build_random_cameras(n_views, dist=2.10, generator=None):
-
-    cos_elevs = torch.rand(n_views, generator=generator) * 2 - 1
-    elevs = torch.acos(cos_elevs) * 180 / torch.pi - 90
-
-    azims = torch.rand(n_views, generator=generator) * 360 - 180
-
-    R_list, T_list = look_at_view_transform(dist = dist, elev = elevs, azim = azims, at=((0, 0.10, 0.25),))
-
-    return FoVPerspectiveCameras(R=R_list, T=T_list, device=device)
-
-
-def setup_optimizations(optimization_target, mesh, lr):
-
-    optimizable_mesh = mesh.clone()
-
-    texture_map = optimizable_mesh.textures.maps_padded()
-    verts = optimizable_mesh.verts_packed()
-    faces = optimizable_mesh.faces_packed()
-    verts_uvs = optimizable_mesh.textures.verts_uvs_padded()
-    faces_uvs = optimizable_mesh.textures.faces_uvs_padded()
-
-    if optimization_target == 'texture':
-        texture_map.requires_grad_(True)
-        optimizer = _st3d_optim.Adam([texture_map], lr=lr)
-
-    elif optimization_target == 'mesh':
-        verts.requires_grad_(True)
-        optimizer = _st3d_optim.Adam([verts], lr=lr)
-
-    elif optimization_target == 'both':
-        texture_map.requires_grad_(True)
-        verts.requires_grad_(True)
-        optimizer = _st3d_optim.Adam([verts, texture_map], lr = lr)
-
-    return {'optimizable_mesh': optimizable_mesh,
-            'optimizer': optimizer,
-            'texture_map': texture_map,
-            'verts': verts,
-            'faces': faces,
-            'verts_uvs': verts_uvs,
-            'faces_uvs': faces_uvs
-            }
+def finalize_mesh(mesh):
+    """Same geometry and UVs, texture clamped to displayable range and detached (:95-104)."""
+    tex = mesh.textures
+    clamped = TexturesUV(maps=finalize_tensor(tex.maps_padded()), faces_uvs=tex.faces_uvs_padded(),
+                         verts_uvs=tex.verts_uvs_padded())
+    return Meshes(verts=mesh.verts_padded(), faces=mesh.faces_padded(), textures=clamped)
 
 
 def build_mesh(verts_uvs, faces_uvs, texture_map, verts, faces):
-    textures = TexturesUV(verts_uvs=verts_uvs, faces_uvs=faces_uvs, maps=texture_map)
-    mesh = Meshes(verts=[verts], faces=[faces], textures=textures)
-    return mesh
+    """Fresh containers around the (possibly leaf) tensors, rebuilt every step like the reference (:207-210)."""
+    return Meshes(verts=[verts], faces=[faces],
+                  textures=TexturesUV(maps=texture_map, faces_uvs=faces_uvs, verts_uvs=verts_uvs))
+
+
+# ------------------------------------------------------------------------------------------ cameras
+def build_fixed_cameras(n_views, dist=3.0, shuffle=True):
+    """Turntable: the first n//2 views rotate the object about X by linspace(0,315), the rest about Y by
+    linspace(45,315); the camera sits at T=(0,0,dist); order shuffled with Python's RNG (:121-151)."""
+    n_x = n_views // 2
+    plan = [("X", float(a)) for a in torch.linspace(0, 315, n_x)]
+    plan += [("Y", float(a)) for a in torch.linspace(45, 315, n_views - n_x)]
+    if shuffle:
+        random.shuffle(plan)
+    rot = [RotateAxisAngle(angle, axis=axis).get_matrix()[0, :3, :3] for axis, angle in plan]
+    R = torch.stack(rot) if rot else torch.zeros(0, 3, 3)
+    T = torch.tensor([0.0, 0.0, dist]).expand(len(plan), 3).clone()
+    return FoVPerspectiveCameras(R=R, T=T, device=device)
+
+
+def build_random_cameras(n_views, dist=2.10, generator=None):
+    """Uniform directions on the sphere around the look-at point (0, 0.10, 0.25): cos(polar) ~ U(-1,1),
+    azimuth ~ U(-180,180) degrees (:154-170).  `generator` seeds the draws (the reference is unseeded)."""
+    u = torch.rand(n_views, generator=generator)
+    elev = torch.acos(2.0 * u - 1.0) * 180 / torch.pi - 90        # same op order as the reference: bit-equal angles
+    azim = 360.0 * torch.rand(n_views, generator=generator) - 180.0
+    R, T = look_at_view_transform(dist=dist, elev=elev, azim=azim, at=((0, 0.10, 0.25),))
+    return FoVPerspectiveCameras(R=R, T=T, device=device)
+
+
+# ------------------------------------------------------------------------------------------ optimiser
+_LEAVES = {'texture': ('texture_map',), 'mesh': ('verts',), 'both': ('verts', 'texture_map')}
+
+
+def setup_optimizations(optimization_target, mesh, lr):
+    """Clone the mesh, mark the tensors `optimization_target` names as leaves and put ONE Adam (single lr,
+    default betas/eps) over them (:173-204).  Keys of the returned dict are the reference's."""
+    work = mesh.clone()
+    parts = {
+        'texture_map': work.textures.maps_padded(),
+        'verts': work.verts_packed(),
+        'faces': work.faces_packed(),
+        'verts_uvs': work.textures.verts_uvs_padded(),
+        'faces_uvs': work.textures.faces_uvs_padded(),
+    }
+    if optimization_target not in _LEAVES:      # the reference falls through to an unbound `optimizer`
+        raise UnboundLocalError("local variable 'optimizer' referenced before assignment "
+                                f"(optimization_target={optimization_target!r})")
+    leaves = [parts[name].requires_grad_(True) for name in _LEAVES[optimization_target]]
+    return dict(parts, optimizable_mesh=work, optimizer=_st3d_optim.Adam(leaves, lr=lr))
