@@ -27,7 +27,7 @@ SOURCES = {
     "raster.hip": ["-ffp-contract=off"],
     "shade.hip": ["-ffp-contract=off"],
     "soft.hip": ["-ffp-contract=off"],
-    "conv.hip": [],
+    "conv.hip": ["-fno-slp-vectorize"],   # the VALU conv1_1 kernels: SLP-packed v_pk_fma needs register-pair shuffles
     "wino.hip": ["-fno-slp-vectorize"],   # SLP-packed f32 (v_pk_*) needs register shuffles that cost matrix-pipe time
     "gram.hip": [],
     "loss.hip": ["-ffp-contract=off"],

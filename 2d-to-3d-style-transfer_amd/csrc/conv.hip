@@ -246,65 +246,191 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float *__restrict__ 
     if (idx) idx[i] = (uint8_t)bi;
 }
 
-// Input gradient of a conv with <= 4 INPUT channels (conv1_1: 64 -> 3 at full resolution).  With
-// M = 3 the implicit GEMM would waste 29/32 of every MFMA, and the layer is HBM-bound anyway
-// (reads the 64-channel gradient + its ReLU gate: 2 x 64 x H x W x 4 B, writes 3 x H x W x 4 B),
-// so it runs on the vector ALU: one thread per pixel, 3 accumulators, the gated gradient tile
-// [8][10][34] staged in LDS with 16-byte loads, weights read as scalars (wave-uniform).
-// wd is the dgrad pack [tap'][CoutP4][CinP128] of pack_kernel.
-constexpr int SG_KC = 8, SG_TH = 8, SG_PCP = 40;     // LDS row pitch 40: columns x0-4 .. x0+35
+// Input gradient of a conv with 3 INPUT channels (conv1_1: 64 -> 3 at full resolution).  With M = 3 the implicit
+// GEMM would waste 29/32 of every MFMA, and the layer is HBM-bound anyway (reads the 64-channel gradient + its ReLU
+// gate: 2 x 64 x H x W x 4 B, writes 3 x H x W x 4 B), so it runs on the vector ALU.  A 256-thread workgroup owns an
+// 8 x 128-pixel tile, every thread 4 consecutive pixels x 3 channels = 12 accumulators: per input channel it reads its
+// 3 x 6 gated-gradient window with 9 LDS instructions and the 27 weights with 7 broadcast reads for 108 FMAs.  The
+// gated gradient of the NEXT 4 channels is fetched into registers (16-byte loads) while the current 4 are consumed.
+// wd is the dgrad pack [tap'][CoutP4][CinP128] of pack_kernel; it is re-laid [cout][tap'][3 (+1 pad)] in LDS once.
+constexpr int SG_KC = 4, SG_TH = 8, SG_TW = 128, SG_PCP = 140;     // LDS row: columns x0-4 .. x0+131 (+ pad)
 template <int CI>
 __global__ __launch_bounds__(256) void dgrad_small_kernel(const float *__restrict__ gy, const float *__restrict__ act,
                                                           const float *__restrict__ wd, float *__restrict__ gx, int Cout,
                                                           int CoutP4, int H, int W, int tiles_x) {
-    __shared__ __attribute__((aligned(16))) float tile[SG_KC][SG_TH + 2][SG_PCP];
+    static_assert(CI == 3, "conv1_1 only");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float(*tile)[SG_TH + 2][SG_PCP] = reinterpret_cast<float(*)[SG_TH + 2][SG_PCP]>(smem);      // [SG_KC]
+    float *wl = smem + SG_KC * (SG_TH + 2) * SG_PCP;                                              // [Cout][28]
     const int tid = threadIdx.x;
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, n = blockIdx.y;
-    const int x0 = tx * 32, y0 = ty * SG_TH;
+    const int x0 = tx * SG_TW, y0 = ty * SG_TH;
     const int px = tid & 31, py = tid >> 5;
     const size_t HW = (size_t)H * W;
     const float *gb = gy + (size_t)n * Cout * HW;
     const float *ab = act ? act + (size_t)n * Cout * HW : nullptr;
-    // staging items: 8 channels x 10 rows x 10 float4 (columns x0-4+4l .. +3); W % 4 == 0 so an item is
-    // entirely inside or outside the image
-    constexpr int ITEMS = SG_KC * (SG_TH + 2) * 10;
-    float acc[CI];
+    for (int e = tid; e < Cout * 28; e += 256) {
+        const int c = e / 28, r = e - c * 28, tap = r / 3, i = r - tap * 3;
+        wl[e] = (r < 27) ? wd[((size_t)tap * CoutP4 + c) * 128 + i] : 0.f;
+    }
+    // staging items: SG_KC channels x 10 rows x 34 float4 (columns x0-4+4l .. +3); W % 4 == 0 so an item is entirely
+    // inside or outside the image
+    constexpr int ROW4 = (SG_TW + 8) / 4;
+    constexpr int ITEMS = SG_KC * (SG_TH + 2) * ROW4;
+    constexpr int NIT = (ITEMS + 255) / 256;
+    float acc[4][CI];
 #pragma unroll
-    for (int i = 0; i < CI; ++i) acc[i] = 0.f;
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int i = 0; i < CI; ++i) acc[p][i] = 0.f;
+    f32x4 rg[NIT], ra[NIT];
+    auto fetch = [&](int c0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) {
+            const int e = tid + 256 * j;
+            const int ci = e / ((SG_TH + 2) * ROW4), rem = e - ci * ((SG_TH + 2) * ROW4), r = rem / ROW4, l = rem - r * ROW4;
+            const int yy = y0 + r - 1, xx = x0 - 4 + 4 * l;
+            const bool ok = e < ITEMS && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const size_t o = ok ? (size_t)(c0 + ci) * HW + (size_t)yy * W + xx : 0;     // always a valid address
+            rg[j] = *reinterpret_cast<const f32x4 *>(gb + o);
+            ra[j] = ab ? *reinterpret_cast<const f32x4 *>(ab + o) : f32x4{1.f, 1.f, 1.f, 1.f};
+            if (!ok) ra[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    fetch(0);
     for (int c0 = 0; c0 < Cout; c0 += SG_KC) {
         __syncthreads();
-        for (int e = tid; e < ITEMS; e += 256) {
-            const int ci = e / 100, rem = e - ci * 100, r = rem / 10, l = rem - r * 10;
-            const int yy = y0 + r - 1, xx = x0 - 4 + 4 * l;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (yy >= 0 && yy < H && xx >= 0 && xx < W && c0 + ci < Cout) {
-                const size_t o = (size_t)(c0 + ci) * HW + (size_t)yy * W + xx;
-                v = *reinterpret_cast<const float4 *>(gb + o);
-                if (ab) {
-                    const float4 m = *reinterpret_cast<const float4 *>(ab + o);
-                    v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
-                    v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
-                }
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) {
+            const int e = tid + 256 * j;
+            if (e < ITEMS) {
+                const int ci = e / ((SG_TH + 2) * ROW4), rem = e - ci * ((SG_TH + 2) * ROW4), r = rem / ROW4, l = rem - r * ROW4;
+                f32x4 v;
+                v.x = ra[j].x > 0.f ? rg[j].x : 0.f; v.y = ra[j].y > 0.f ? rg[j].y : 0.f;
+                v.z = ra[j].z > 0.f ? rg[j].z : 0.f; v.w = ra[j].w > 0.f ? rg[j].w : 0.f;
+                *reinterpret_cast<f32x4 *>(&tile[ci][r][4 * l]) = v;
             }
-            *reinterpret_cast<float4 *>(&tile[ci][r][4 * l]) = v;
         }
         __syncthreads();
+        if (c0 + SG_KC < Cout) fetch(c0 + SG_KC);
 #pragma unroll
         for (int c = 0; c < SG_KC; ++c) {
+            float w[28];
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int ky = tap / 3, kx = tap - ky * 3;
-                const float v = tile[c][py + ky][px + kx + 3];        // column x0-1+px+kx sits at LDS column +3
-                const float *wr = wd + ((size_t)tap * CoutP4 + (c0 + c)) * 128;   // wave-uniform: scalar loads
+            for (int q = 0; q < 7; ++q) {
+                const f32x4 t = *reinterpret_cast<const f32x4 *>(wl + (c0 + c) * 28 + 4 * q);      // same address in every lane
+                w[4 * q] = t.x; w[4 * q + 1] = t.y; w[4 * q + 2] = t.z; w[4 * q + 3] = t.w;
+            }
 #pragma unroll
-                for (int i = 0; i < CI; ++i) acc[i] += v * wr[i];
+            for (int ky = 0; ky < 3; ++ky) {
+                // window columns x-1 .. x+4 of the thread's 4 pixels sit at LDS columns 4px+3 .. 4px+8
+                const float *row = &tile[c][py + ky][4 * px];
+                const float l = row[3];
+                const f32x4 m = *reinterpret_cast<const f32x4 *>(row + 4);
+                const float r = row[8];
+                const float v[6] = {l, m.x, m.y, m.z, m.w, r};
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+#pragma unroll
+                        for (int i = 0; i < CI; ++i) acc[p][i] += v[p + kx] * w[(ky * 3 + kx) * 3 + i];
             }
         }
     }
-    const int ox = x0 + px, oy = y0 + py;
-    if (ox < W && oy < H) {
+    const int oy = y0 + py, ox = x0 + 4 * px;
+    if (oy < H && ox < W) {                     // W % 4 == 0: the 4 pixels are inside together
 #pragma unroll
-        for (int i = 0; i < CI; ++i) gx[((size_t)n * CI + i) * HW + (size_t)oy * W + ox] = acc[i];
+        for (int i = 0; i < CI; ++i)
+            *reinterpret_cast<f32x4 *>(gx + ((size_t)n * CI + i) * HW + (size_t)oy * W + ox) =
+                f32x4{acc[0][i], acc[1][i], acc[2][i], acc[3][i]};
+    }
+}
+
+// Forward of a conv with 3 INPUT channels (conv1_1: 3 -> 64 at full resolution): K = 27 cannot feed the matrix pipe
+// (the direct MFMA kernel pads K to 36 and spends its time in prologue/epilogue), and the layer only has to stream
+// its 64-channel output, so it runs on the vector ALU too.  Same geometry as dgrad_small_kernel: 8 x 128-pixel tile,
+// 4 consecutive pixels per thread; the 3-channel haloed patch is staged once, the thread keeps its 3 x 3 x 6 window
+// in registers and walks the output channels 16 at a time (64 accumulators): per weight row one 16-float broadcast
+// read for 64 FMAs; bias + ReLU fused; 16-byte stores.  wf is the forward pack [tap][CinP4][CoutP128].
+constexpr int SF_CG = 16;
+__global__ __launch_bounds__(256, 2) void conv_small_fwd_kernel(const float *__restrict__ x, const float *__restrict__ wf,
+                                                             const float *__restrict__ bias, float *__restrict__ y, int Cout,
+                                                             int CoutP, int H, int W, int tiles_x, int relu) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float(*tile)[SG_TH + 2][SG_PCP] = reinterpret_cast<float(*)[SG_TH + 2][SG_PCP]>(smem);      // [3]
+    float *wl = smem + 3 * (SG_TH + 2) * SG_PCP;                                                 // [27][Cout], k = (ci*3+ky)*3+kx
+    const int tid = threadIdx.x;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, n = blockIdx.y;
+    const int x0 = tx * SG_TW, y0 = ty * SG_TH;
+    const int px = tid & 31, py = tid >> 5;
+    const size_t HW = (size_t)H * W;
+    const float *xb = x + (size_t)n * 3 * HW;
+    for (int e = tid; e < 27 * Cout; e += 256) {
+        const int k = e / Cout, co = e - k * Cout, ci = k / 9, tap = k - ci * 9;
+        wl[e] = wf[((size_t)tap * 4 + ci) * CoutP + co];
+    }
+    constexpr int ROW4 = (SG_TW + 8) / 4;
+    constexpr int ITEMS = 3 * (SG_TH + 2) * ROW4;
+    for (int e = tid; e < ITEMS; e += 256) {
+        const int ci = e / ((SG_TH + 2) * ROW4), rem = e - ci * ((SG_TH + 2) * ROW4), r = rem / ROW4, l = rem - r * ROW4;
+        const int yy = y0 + r - 1, xx = x0 - 4 + 4 * l;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = *reinterpret_cast<const f32x4 *>(xb + (size_t)ci * HW + (size_t)yy * W + xx);
+        *reinterpret_cast<f32x4 *>(&tile[ci][r][4 * l]) = v;
+    }
+    __syncthreads();
+    float win[9][6];        // [row = ci*3+ky][column x-1 .. x+4]
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const float *row = &tile[ci][py + ky][4 * px];
+            const f32x4 m = *reinterpret_cast<const f32x4 *>(row + 4);
+            float *w6 = win[ci * 3 + ky];
+            w6[0] = row[3]; w6[1] = m.x; w6[2] = m.y; w6[3] = m.z; w6[4] = m.w; w6[5] = row[8];
+        }
+    const int oy = y0 + py, ox = x0 + 4 * px;
+    const bool inside = oy < H && ox < W;
+    for (int cg = 0; cg < Cout; cg += SF_CG) {
+        float acc[SF_CG][4];
+#pragma unroll
+        for (int j = 0; j < SF_CG; ++j) {
+            const float bv = bias ? bias[cg + j] : 0.f;
+            acc[j][0] = bv; acc[j][1] = bv; acc[j][2] = bv; acc[j][3] = bv;
+        }
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {           // r = ci*3 + ky
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float *wrow = wl + (r * 3 + kx) * Cout + cg;          // same address in every lane
+#pragma unroll
+                for (int q = 0; q < SF_CG / 4; ++q) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4 *>(wrow + 4 * q);
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        acc[4 * q][p] += win[r][p + kx] * wv.x;
+                        acc[4 * q + 1][p] += win[r][p + kx] * wv.y;
+                        acc[4 * q + 2][p] += win[r][p + kx] * wv.z;
+                        acc[4 * q + 3][p] += win[r][p + kx] * wv.w;
+                    }
+                }
+            }
+            // pin the schedule per window row: without this the compiler reads all 27 weight rows up front and
+            // spills them (the accumulators pass through an empty asm, so this row's FMAs end here and the next
+            // row's LDS reads start after it)
+#pragma unroll
+            for (int j = 0; j < SF_CG; ++j)
+                asm volatile("" : "+v"(acc[j][0]), "+v"(acc[j][1]), "+v"(acc[j][2]), "+v"(acc[j][3]) : : "memory");
+        }
+        if (inside) {
+#pragma unroll
+            for (int j = 0; j < SF_CG; ++j) {
+                f32x4 o = {acc[j][0], acc[j][1], acc[j][2], acc[j][3]};
+                if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+                *reinterpret_cast<f32x4 *>(y + ((size_t)n * Cout + cg + j) * HW + (size_t)oy * W + ox) = o;
+            }
+        }
     }
 }
 
@@ -354,6 +480,14 @@ extern "C" int st3d_conv3x3_fwd(const float *x, const float *w_fwd_packed, const
     ST3D_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0);
     ST3D_CHECK_ARG((size_t)Cin * H * W < (1u << 31) && (size_t)Cout * H * W < (1u << 31));
     ST3D_CHECK_ARG(((uintptr_t)w_fwd_packed & 15) == 0);
+    if (Cin == 3 && (W % 4) == 0 && (Cout % SF_CG) == 0 && Cout <= 128) {          // conv1_1: VALU kernel
+        const int tiles_x = st3d::cdiv(W, SG_TW);
+        const size_t lds = ((size_t)3 * (SG_TH + 2) * SG_PCP + (size_t)27 * Cout) * sizeof(float);
+        conv_small_fwd_kernel<<<dim3(tiles_x * st3d::cdiv(H, SG_TH), N), 256, lds, st3d::as_stream(stream)>>>(
+            x, w_fwd_packed, bias, y, Cout, ceil_to(Cout, 128), H, W, tiles_x, relu);
+        ST3D_LAUNCH_CHECK();
+        return ST3D_OK;
+    }
     ConvArgs a{x, nullptr, nullptr, w_fwd_packed, bias, y, N, Cin, Cout, H, W, ceil_to(Cin, 4), ceil_to(Cout, 128), relu, 0};
     return launch_conv<0>(a, st3d::as_stream(stream));
 }
@@ -364,9 +498,10 @@ extern "C" int st3d_conv3x3_dgrad(const float *gy, const float *act, const float
     ST3D_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0);
     ST3D_CHECK_ARG((size_t)Cin * H * W < (1u << 31) && (size_t)Cout * H * W < (1u << 31));
     ST3D_CHECK_ARG(((uintptr_t)w_dgrad_packed & 15) == 0);
-    if (Cin == 3 && (W % 4) == 0 && (Cout % SG_KC) == 0 && ceil_to(Cin, 128) == 128) {     // conv1_1: HBM-bound VALU kernel
-        const int tiles_x = st3d::cdiv(W, 32);
-        dgrad_small_kernel<3><<<dim3(tiles_x * st3d::cdiv(H, SG_TH), N), 256, 0, st3d::as_stream(stream)>>>(
+    if (Cin == 3 && (W % 4) == 0 && (Cout % SG_KC) == 0 && Cout <= 256 && ceil_to(Cin, 128) == 128) {     // conv1_1: VALU kernel
+        const int tiles_x = st3d::cdiv(W, SG_TW);
+        const size_t lds = ((size_t)SG_KC * (SG_TH + 2) * SG_PCP + (size_t)Cout * 28) * sizeof(float);
+        dgrad_small_kernel<3><<<dim3(tiles_x * st3d::cdiv(H, SG_TH), N), 256, lds, st3d::as_stream(stream)>>>(
             gy, act, w_dgrad_packed, gx, Cout, ceil_to(Cout, 4), H, W, tiles_x);
         ST3D_LAUNCH_CHECK();
         return ST3D_OK;

@@ -167,20 +167,31 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         }
 }
 
-// G[b][i][j] = sum over splits (in order) of the slab element; tiles below the diagonal are
-// read transposed from the mirrored tile.
+// G[b][i][j] = sum over the split slabs of the element, in a FIXED tree (4 interleaved partial sums per element, each
+// over its slabs in ascending order, then ((p0+p1)+(p2+p3))) -- bitwise reproducible, and four times the loads in
+// flight of a single running sum.  Tiles below the diagonal are read transposed from the mirrored tile.
 __global__ __launch_bounds__(256) void gram_reduce_kernel(const float *__restrict__ slab, int nsplit, int C, int TM,
                                                           size_t sSplit, size_t sB, float *__restrict__ gram) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float part[4][64];
+    const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const size_t i = (size_t)blockIdx.x * 64 + e;
     const size_t CC = (size_t)C * C;
-    if (i >= CC) return;
     const int b = blockIdx.y;
-    int r = i / C, c = i % C;
-    if (r / TM > c / TM) { const int t = r; r = c; c = t; }
-    const float *p = slab + b * sB + (size_t)r * C + c;
     float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += p[k * sSplit];
-    gram[b * CC + i] = s;
+    if (i < CC) {
+        int r = i / C, c = i % C;
+        if (r / TM > c / TM) { const int t = r; r = c; c = t; }
+        const float *p = slab + b * sB + (size_t)r * C + c;
+        int k = q;
+        for (; k + 12 < nsplit; k += 16) {
+            const float a0 = p[k * sSplit], a1 = p[(k + 4) * sSplit], a2 = p[(k + 8) * sSplit], a3 = p[(k + 12) * sSplit];
+            s += a0; s += a1; s += a2; s += a3;
+        }
+        for (; k < nsplit; k += 4) s += p[k * sSplit];
+    }
+    part[q][e] = s;
+    __syncthreads();
+    if (q == 0 && i < CC) gram[b * CC + i] = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
 }
 
 // K split: enough workgroups to fill the chip twice over (256 CUs x 2 resident workgroups x 2), but
@@ -230,7 +241,7 @@ extern "C" int st3d_gram_fwd(const float *feat, int B, int C, int HW, void *work
     if (TM == 128) gemm_kernel<2, 2, 0><<<grid, 256, 0, s>>>(g);
     else gemm_kernel<1, 1, 0><<<grid, 256, 0, s>>>(g);
     ST3D_LAUNCH_CHECK();
-    gram_reduce_kernel<<<dim3(st3d::cdiv((long)C * C, 256), B), 256, 0, s>>>(g.C, g.nsplit, C, TM, g.sSplit, g.sC, gram);
+    gram_reduce_kernel<<<dim3(st3d::cdiv((long)C * C, 64), B), 256, 0, s>>>(g.C, g.nsplit, C, TM, g.sSplit, g.sC, gram);
     ST3D_LAUNCH_CHECK();
     return ST3D_OK;
 }
