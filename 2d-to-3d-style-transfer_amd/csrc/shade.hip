@@ -91,60 +91,93 @@ __global__ __launch_bounds__(256) void shade_fwd_kernel(const int32_t *__restric
     mask[i] = ((1.0f - (1.0f - bl.prob)) > 0.f) ? 1.f : 0.f;
 }
 
+// Texture-sampling backward.  One workgroup per 16x16-pixel tile of one view.  The <= 12 bilinear contributions of a
+// pixel are not sent to HBM one float atomic each (neighbouring pixels hit the same texels: ~6 M contended L2 atomics
+// per step at config 2): they are first summed per texel in an LDS table (open addressing on the texel index,
+// ds_add_f32) and each distinct texel of the tile then costs three global atomics.  d/d(u,v) and d/d(bary) (vertex
+// path) are per-pixel outputs written directly.
+constexpr int kTexSlots = 2048;          // >= 4 x 256 footprint corners: the probe always terminates
+
 __global__ __launch_bounds__(256) void shade_bwd_kernel(const float *__restrict__ grad_rgb, const int32_t *__restrict__ p2f,
                                                         const float *__restrict__ bary, const float *__restrict__ zbuf,
                                                         const float *__restrict__ dists, const float *__restrict__ uvs,
                                                         const int32_t *__restrict__ fuv, const float *__restrict__ tex,
-                                                        int B, int S, int T, float *__restrict__ gtex,
+                                                        int B, int S, int T, int tiles_x, float *__restrict__ gtex,
                                                         float *__restrict__ guv, float *__restrict__ gbary) {
+    __shared__ int s_key[kTexSlots];
+    __shared__ float s_acc[kTexSlots][3];
+    const int tid = threadIdx.x;
+    if (gtex) {
+        for (int e = tid; e < kTexSlots; e += 256) s_key[e] = -1;
+        for (int e = tid; e < kTexSlots * 3; e += 256) (&s_acc[0][0])[e] = 0.f;
+        __syncthreads();
+    }
     const size_t HW = (size_t)S * S;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)B * HW) return;
-    const size_t b = i / HW, p = i - b * HW;
-    const int f = p2f[i];
-    if (f < 0) {
+    const int b = blockIdx.y;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int yi = ty * 16 + (tid >> 4), xi = tx * 16 + (tid & 15);
+    const bool in_img = yi < S && xi < S;
+    const size_t p = (size_t)yi * S + xi, i = (size_t)b * HW + p;
+    const int f = in_img ? p2f[i] : -1;
+    if (in_img && f < 0) {
         if (guv) { guv[2 * i] = 0.f; guv[2 * i + 1] = 0.f; }
         if (gbary) { gbary[3 * i] = 0.f; gbary[3 * i + 1] = 0.f; gbary[3 * i + 2] = 0.f; }
-        return;
     }
-    const bool want_uv = guv || gbary;
-    const float b0 = bary[3 * i], b1 = bary[3 * i + 1], b2 = bary[3 * i + 2];
-    const int u0 = fuv[3 * f], u1 = fuv[3 * f + 1], u2 = fuv[3 * f + 2];
-    const float u = b0 * uvs[2 * u0] + b1 * uvs[2 * u1] + b2 * uvs[2 * u2];
-    const float v = b0 * uvs[2 * u0 + 1] + b1 * uvs[2 * u1 + 1] + b2 * uvs[2 * u2 + 1];
-    const Footprint q = uv_footprint(u, v, T);
-    const Blend bl = blend_k1(dists[i], zbuf[i]);
-    const float k = bl.wnum / bl.denom;
-    const float w00 = q.wx0 * q.wy0, w01 = q.wx1 * q.wy0, w10 = q.wx0 * q.wy1, w11 = q.wx1 * q.wy1;
-    const size_t o00 = ((size_t)q.r0 * T + q.x0) * 3, o01 = ((size_t)q.r0 * T + q.x1) * 3;
-    const size_t o10 = ((size_t)q.r1 * T + q.x0) * 3, o11 = ((size_t)q.r1 * T + q.x1) * 3;
-    const float *g = grad_rgb + b * 3 * HW + p;
-    float gix = 0.f, giy = 0.f;
-    const float gk[3] = {g[0] * k, g[HW] * k, g[2 * HW] * k};
-    if (want_uv) {      // texel reads before any atomic: on gfx9 a load queued behind atomics returns after them
+    if (f >= 0) {
+        const bool want_uv = guv || gbary;
+        const float b0 = bary[3 * i], b1 = bary[3 * i + 1], b2 = bary[3 * i + 2];
+        const int u0 = fuv[3 * f], u1 = fuv[3 * f + 1], u2 = fuv[3 * f + 2];
+        const float u = b0 * uvs[2 * u0] + b1 * uvs[2 * u1] + b2 * uvs[2 * u2];
+        const float v = b0 * uvs[2 * u0 + 1] + b1 * uvs[2 * u1 + 1] + b2 * uvs[2 * u2 + 1];
+        const Footprint q = uv_footprint(u, v, T);
+        const Blend bl = blend_k1(dists[i], zbuf[i]);
+        const float k = bl.wnum / bl.denom;
+        const float w00 = q.wx0 * q.wy0, w01 = q.wx1 * q.wy0, w10 = q.wx0 * q.wy1, w11 = q.wx1 * q.wy1;
+        const int e00 = q.r0 * T + q.x0, e01 = q.r0 * T + q.x1, e10 = q.r1 * T + q.x0, e11 = q.r1 * T + q.x1;
+        const float *g = grad_rgb + (size_t)b * 3 * HW + p;
+        const float gk[3] = {g[0] * k, g[HW] * k, g[2 * HW] * k};
+        if (want_uv) {
+            float gix = 0.f, giy = 0.f;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float t00 = (q.vy0 && q.vx0) ? tex[o00 + c] : 0.f, t01 = (q.vy0 && q.vx1) ? tex[o01 + c] : 0.f;
-            const float t10 = (q.vy1 && q.vx0) ? tex[o10 + c] : 0.f, t11 = (q.vy1 && q.vx1) ? tex[o11 + c] : 0.f;
-            gix += gk[c] * ((t01 - t00) * q.wy0 + (t11 - t10) * q.wy1);
-            giy += gk[c] * ((t10 - t00) * q.wx0 + (t11 - t01) * q.wx1);
+            for (int c = 0; c < 3; ++c) {
+                const float t00 = (q.vy0 && q.vx0) ? tex[(size_t)e00 * 3 + c] : 0.f, t01 = (q.vy0 && q.vx1) ? tex[(size_t)e01 * 3 + c] : 0.f;
+                const float t10 = (q.vy1 && q.vx0) ? tex[(size_t)e10 * 3 + c] : 0.f, t11 = (q.vy1 && q.vx1) ? tex[(size_t)e11 * 3 + c] : 0.f;
+                gix += gk[c] * ((t01 - t00) * q.wy0 + (t11 - t10) * q.wy1);
+                giy += gk[c] * ((t10 - t00) * q.wx0 + (t11 - t01) * q.wx1);
+            }
+            const float gu = q.cx ? 0.f : gix * (float)(T - 1);
+            const float gv = q.cy ? 0.f : giy * (float)(T - 1);
+            if (guv) { guv[2 * i] = gu; guv[2 * i + 1] = gv; }
+            if (gbary) {      // uv = sum_i b_i * uv_i
+                gbary[3 * i] = gu * uvs[2 * u0] + gv * uvs[2 * u0 + 1];
+                gbary[3 * i + 1] = gu * uvs[2 * u1] + gv * uvs[2 * u1 + 1];
+                gbary[3 * i + 2] = gu * uvs[2 * u2] + gv * uvs[2 * u2 + 1];
+            }
+        }
+        if (gtex) {
+            auto deposit = [&](int texel, float w) __attribute__((always_inline)) {
+                int slot = (int)(((unsigned)texel * 2654435761u) >> 21) & (kTexSlots - 1);
+                for (;;) {
+                    const int prev = atomicCAS(&s_key[slot], -1, texel);
+                    if (prev == -1 || prev == texel) break;
+                    slot = (slot + 1) & (kTexSlots - 1);
+                }
+                atomicAdd(&s_acc[slot][0], gk[0] * w); atomicAdd(&s_acc[slot][1], gk[1] * w); atomicAdd(&s_acc[slot][2], gk[2] * w);
+            };
+            if (q.vy0 && q.vx0) deposit(e00, w00);
+            if (q.vy0 && q.vx1) deposit(e01, w01);
+            if (q.vy1 && q.vx0) deposit(e10, w10);
+            if (q.vy1 && q.vx1) deposit(e11, w11);
         }
     }
-    const float gu = q.cx ? 0.f : gix * (float)(T - 1);
-    const float gv = q.cy ? 0.f : giy * (float)(T - 1);
-    if (guv) { guv[2 * i] = gu; guv[2 * i + 1] = gv; }
-    if (gbary) {      // uv = sum_i b_i * uv_i
-        gbary[3 * i] = gu * uvs[2 * u0] + gv * uvs[2 * u0 + 1];
-        gbary[3 * i + 1] = gu * uvs[2 * u1] + gv * uvs[2 * u1 + 1];
-        gbary[3 * i + 2] = gu * uvs[2 * u2] + gv * uvs[2 * u2 + 1];
-    }
     if (gtex) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            if (q.vy0 && q.vx0) atomicAdd(gtex + o00 + c, gk[c] * w00);
-            if (q.vy0 && q.vx1) atomicAdd(gtex + o01 + c, gk[c] * w01);
-            if (q.vy1 && q.vx0) atomicAdd(gtex + o10 + c, gk[c] * w10);
-            if (q.vy1 && q.vx1) atomicAdd(gtex + o11 + c, gk[c] * w11);
+        __syncthreads();
+        for (int e = tid; e < kTexSlots * 3; e += 256) {
+            const int slot = e / 3, c = e - slot * 3;
+            const int texel = s_key[slot];
+            if (texel < 0) continue;
+            const float v = s_acc[slot][c];
+            if (v != 0.f) atomicAdd(gtex + (size_t)texel * 3 + c, v);
         }
     }
 }
@@ -184,8 +217,9 @@ extern "C" int st3d_shade_bwd(const float *grad_rgb, const int32_t *pix_to_face,
     ST3D_CHECK_ARG(grad_texture || grad_uv || grad_bary);
     ST3D_CHECK_ARG(B > 0 && S > 0 && T > 1 && F > 0 && VT > 0);
     const size_t n = (size_t)B * S * S;
-    shade_bwd_kernel<<<st3d::cdiv((long)n, 256), 256, 0, st3d::as_stream(stream)>>>(
-        grad_rgb, pix_to_face, bary, zbuf, dists, verts_uvs, faces_uvs, texture, B, S, T, grad_texture, grad_uv, grad_bary);
+    const int tiles = (S + 15) / 16;
+    shade_bwd_kernel<<<dim3(tiles * tiles, B), 256, 0, st3d::as_stream(stream)>>>(
+        grad_rgb, pix_to_face, bary, zbuf, dists, verts_uvs, faces_uvs, texture, B, S, T, tiles, grad_texture, grad_uv, grad_bary);
     ST3D_LAUNCH_CHECK();
     return ST3D_OK;
 }

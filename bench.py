@@ -238,8 +238,10 @@ def main():
         step_s = dev_ms / args.steps * 1e-3
         std_cfg = S == 512 and Bv == 8 and not args.no_hoist and wino
         traffic = {}
-        tpath = os.path.join(ROOT, "profiles", "r01_c_pmc_traffic.json")
-        if os.path.exists(tpath) and std_cfg:
+        import glob
+        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))     # newest round last
+        tpath = tfiles[-1] if tfiles else ""
+        if tpath and std_cfg:
             with open(tpath) as fh:
                 traffic = json.load(fh)
         step_roofline = {
@@ -275,9 +277,9 @@ def main():
                         "region.  It exceeds the fp32 MFMA peak because the kernel is Winograd F(2x2,3x3): 16 instead of 36 "
                         "multiplies per 2x2 outputs, still fp32 products + fp32 accumulation.  executed = MFMA flops actually "
                         "issued (16/36 of the algorithmic count) = matrix-pipe utilisation.  traffic = HBM bytes per launch "
-                        "(average) from the committed PMC passes profiles/r01_c_pmc_traffic.json (FETCH_SIZE raw + WRITE_SIZE; "
+                        "(average) from the committed PMC passes %s (FETCH_SIZE raw + WRITE_SIZE; "
                         "gfx950 under-reports 16-B/lane read streams by up to 2x), not re-measured live."
-                        % (f_conv_alg / 1e9, f_conv_alg / 1e9 / kn, nprof)}
+                        % (f_conv_alg / 1e9, f_conv_alg / 1e9 / kn, nprof, os.path.relpath(tpath, ROOT) if tpath else "(none)")}
         tgt = {"texture": "texture-only optimisation", "mesh": "vertex optimisation", "both": "joint vertex + texture optimisation"}[args.target]
         res = {
             "metric": "style-transfer iters/sec (512x512, 8 views, cow_mesh)",
