@@ -93,6 +93,81 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
     }
 }
 
+// ---- regularisers the reference defines but keeps switched off (losses.py:48-65) and the L2-to-original-texture
+// idea of notes.txt:39: fused forward + gradient, ordered reductions like the rest of this file.
+
+// masked anisotropic L1 total variation: partials[blk] = sum |I(y,x)-I(y+1,x)| m(y,x) m(y+1,x) + (same along x);
+// partials[NPART + blk] = sum of the mask (counted once per pixel, channel 0 lanes only)
+__global__ __launch_bounds__(256) void tv_kernel(const float *__restrict__ img, const float *__restrict__ mask, int B, int C,
+                                                 int H, int W, float *__restrict__ partials) {
+    float acc = 0.f, macc = 0.f;
+    const size_t HW = (size_t)H * W, n = (size_t)B * C * HW;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const size_t bc = i / HW, p = i - bc * HW, b = bc / C;
+        const int y = (int)(p / W), x = (int)(p - (size_t)y * W);
+        const float *mb = mask + b * HW;
+        const float a = img[i], m = mb[p];
+        if (y + 1 < H) acc += fabsf(a - img[i + W]) * (m * mb[p + W]);
+        if (x + 1 < W) acc += fabsf(a - img[i + 1]) * (m * mb[p + 1]);
+        if (bc - b * C == 0) macc += m;
+    }
+    __shared__ float s2[4];
+    macc = wave_sum(macc);
+    if ((threadIdx.x & 63) == 0) s2[threadIdx.x >> 6] = macc;
+    block_store_partial(acc, partials);             // (its barrier also publishes s2)
+    if (threadIdx.x == 0) partials[NPART + blockIdx.x] = (s2[0] + s2[1]) + (s2[2] + s2[3]);
+}
+
+__global__ __launch_bounds__(256) void tv_finish_kernel(const float *__restrict__ partials, int np, float *__restrict__ out) {
+    __shared__ double s[256], sm[256];
+    double v = 0.0, m = 0.0;
+    for (int i = threadIdx.x; i < np; i += 256) { v += (double)partials[i]; m += (double)partials[NPART + i]; }
+    s[threadIdx.x] = v; sm[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { s[threadIdx.x] += s[threadIdx.x + o]; sm[threadIdx.x] += sm[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = (float)(s[0] / sm[0]); out[1] = (float)sm[0]; }
+}
+
+__device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+
+// d loss / d img = (sum of the signs of the four differences the pixel takes part in, each weighted by its mask pair) / sum(mask)
+__global__ __launch_bounds__(256) void tv_grad_kernel(const float *__restrict__ img, const float *__restrict__ mask, int B, int C,
+                                                      int H, int W, const float *__restrict__ loss_and_msum,
+                                                      float *__restrict__ g) {
+    const size_t HW = (size_t)H * W, n = (size_t)B * C * HW;
+    const float inv = 1.0f / loss_and_msum[1];
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const size_t bc = i / HW, p = i - bc * HW, b = bc / C;
+        const int y = (int)(p / W), x = (int)(p - (size_t)y * W);
+        const float *mb = mask + b * HW;
+        const float a = img[i], m = mb[p];
+        float d = 0.f;
+        if (y + 1 < H) d += sgn(a - img[i + W]) * (m * mb[p + W]);
+        if (y > 0) d -= sgn(img[i - W] - a) * (mb[p - W] * m);
+        if (x + 1 < W) d += sgn(a - img[i + 1]) * (m * mb[p + 1]);
+        if (x > 0) d -= sgn(img[i - 1] - a) * (mb[p - 1] * m);
+        g[i] = d * inv;
+    }
+}
+
+// sum relu(t - 1) + relu(-t); gradient +1 above 1, -1 below 0
+__global__ __launch_bounds__(256) void range_kernel(const float *__restrict__ t, size_t n, float *__restrict__ g,
+                                                    float *__restrict__ partials) {
+    float acc = 0.f;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float v = t[i];
+        acc += fmaxf(v - 1.0f, 0.f) + fmaxf(-v, 0.f);
+        if (g) g[i] = v > 1.0f ? 1.0f : (v < 0.f ? -1.0f : 0.f);
+    }
+    block_store_partial(acc, partials);
+}
+
 inline int grid_for(size_t n) {
     size_t b = (n + 255) / 256;
     return (int)(b < 1 ? 1 : (b > NPART ? NPART : b));
@@ -148,6 +223,37 @@ extern "C" int st3d_adam_step(float *param, const float *grad, float *exp_avg, f
     const float bc2_sqrt = (float)sqrt(bc2);
     adam_kernel<<<grid_for(n), 256, 0, st3d::as_stream(stream)>>>(param, grad, exp_avg, exp_avg_sq, n, step_size, bc2_sqrt,
                                                                  beta1, beta2, eps);
+    ST3D_LAUNCH_CHECK();
+    return ST3D_OK;
+}
+
+extern "C" int st3d_tv_loss(const float *images, const float *masks, int B, int C, int H, int W, float *partials,
+                            float *loss_and_mask_sum, float *grad_images, st3d_stream_t stream) {
+    ST3D_CHECK_ARG(images && masks && partials && loss_and_mask_sum);
+    ST3D_CHECK_ARG(B > 0 && C > 0 && H > 0 && W > 0);
+    hipStream_t s = st3d::as_stream(stream);
+    const size_t n = (size_t)B * C * H * W;
+    const int gsz = grid_for(n);
+    tv_kernel<<<gsz, 256, 0, s>>>(images, masks, B, C, H, W, partials);
+    ST3D_LAUNCH_CHECK();
+    tv_finish_kernel<<<1, 256, 0, s>>>(partials, gsz, loss_and_mask_sum);
+    ST3D_LAUNCH_CHECK();
+    if (grad_images) {
+        tv_grad_kernel<<<gsz, 256, 0, s>>>(images, masks, B, C, H, W, loss_and_mask_sum, grad_images);
+        ST3D_LAUNCH_CHECK();
+    }
+    return ST3D_OK;
+}
+
+extern "C" int st3d_range_loss(const float *values, size_t n, float *partials, float *loss_out, float *grad,
+                               st3d_stream_t stream) {
+    ST3D_CHECK_ARG(values && partials && loss_out && n > 0);
+    hipStream_t s = st3d::as_stream(stream);
+    const int gsz = grid_for(n);
+    ST3D_HIP(hipMemsetAsync(loss_out, 0, sizeof(float), s));
+    range_kernel<<<gsz, 256, 0, s>>>(values, n, grad, partials);
+    ST3D_LAUNCH_CHECK();
+    finish_kernel<<<1, 256, 0, s>>>(partials, gsz, 1.0f, loss_out);
     ST3D_LAUNCH_CHECK();
     return ST3D_OK;
 }

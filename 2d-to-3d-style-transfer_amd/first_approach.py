@@ -49,6 +49,8 @@ def main(argv=None):
 
     run.say("Starting optimization...")
     for vb in run.batches():
+        if vb.index < run.progress:         # --resume: these view batches were fitted before the checkpoint
+            continue
         run.say(f"\nBatch {vb.index}")
         n_local = vb.hi - vb.lo
         targets = cams = None
@@ -85,6 +87,7 @@ def main(argv=None):
             run.optimizer.step()
             shown = run.global_sum(loss).item()
             run.log(f'Batch {vb.index}, Step {step}, Loss {shown}')
+        run.maybe_checkpoint(vb.index + 1)
 
     run.export(mesh)
 

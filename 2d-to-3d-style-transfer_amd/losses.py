@@ -57,19 +57,52 @@ def compute_perceptual_loss(current_imgs, content_imgs, style_imgs, model, style
     return _PerceptualFn.apply(current_imgs, plan, float(style_weight), float(content_weight), batch_denom)
 
 
+class _FusedLossFn(torch.autograd.Function):
+    """A loss whose HIP call returns the value and its gradient together: backward only scales."""
+
+    @staticmethod
+    def forward(ctx, x, op, *extra):
+        loss, grad = op(x.detach(), *extra, want_grad=x.requires_grad)
+        ctx.grad, ctx.n_extra = grad, len(extra)
+        return loss[0].clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        g = ctx.grad * grad_out if ctx.grad is not None else None
+        return (g, None) + (None,) * ctx.n_extra
+
+
+def _on_gpu(t):
+    if not t.is_cuda:
+        raise RuntimeError("st3d runs on the GPU (libst3d); got CPU tensors -- there is no CPU fallback")
+    return t.to(torch.float32)
+
+
 def rgb_range_loss(mesh):
-    """Sum of the texture map's excursions outside [0,1] (reference losses.py:48-51).  API only:
-    every call site in the reference is commented out."""
-    tex = mesh.textures.maps_padded()
-    return (torch.relu(tex - 1) + torch.relu(-tex)).sum()
+    """Sum of the texture map's excursions outside [0,1] (reference losses.py:48-51; every call site in the
+    reference is commented out).  One fused launch: value + sign gradient."""
+    tex = _on_gpu(mesh.textures.maps_padded())
+    return _FusedLossFn.apply(tex, _ops.range_loss)
 
 
 def compute_tv_loss(images, masks):
-    """Masked anisotropic L1 total variation / sum(masks) (reference losses.py:55-65).  API only:
-    every call site in the reference is commented out."""
-    dh = (images[..., :-1, :] - images[..., 1:, :]).abs() * (masks[..., :-1, :] * masks[..., 1:, :])
-    dw = (images[..., :, :-1] - images[..., :, 1:]).abs() * (masks[..., :, :-1] * masks[..., :, 1:])
-    return (dh.sum() + dw.sum()) / masks.sum()
+    """Masked anisotropic L1 total variation / sum(masks) (reference losses.py:55-65; call sites commented out
+    there too).  Value and d/d images from one fused pass."""
+    return _FusedLossFn.apply(_on_gpu(images), _ops.tv_loss, _on_gpu(masks).detach())
+
+
+def texture_l2_loss(mesh, original_map):
+    """mean((texture - original)^2): the "l2 regularization w.r.t. the original texture" idea of the reference's
+    notes.txt:39 (not implemented there)."""
+    tex = _on_gpu(mesh.textures.maps_padded())
+    return _FusedLossFn.apply(tex, _l2_to, _on_gpu(original_map).detach())
+
+
+def _l2_to(x, ref, want_grad=True):
+    if not want_grad:
+        return _ops.sqdiff_sum(x, ref.reshape(x.shape), scale=1.0 / x.numel()), None
+    loss, diff = _ops.sqdiff_sum(x, ref.reshape(x.shape), scale=1.0 / x.numel(), want_diff=True)
+    return loss, diff * (2.0 / x.numel())
 
 
 class _MaskedMseFn(torch.autograd.Function):

@@ -21,14 +21,14 @@ from style_transfer import *  # noqa: F401,F403
 from utils import *  # noqa: F401,F403
 from losses import *  # noqa: F401,F403
 
-from st3d.cli import Flag, Run, load_scene, make_parser  # noqa: F401  (load_scene re-exported)
+from st3d.cli import REGULARISER_FLAGS, Flag, Run, load_scene, make_parser  # noqa: F401  (load_scene re-exported)
 
 FLAGS = [
     Flag("epochs", int, 3000, "passes over the view set"),
     Flag("output_path", str, "/content/output_second", "folder for log.txt, renders and the final mesh"),
     Flag("lr", float, 0.01, "Adam step size"),
     Flag("save_every", int, 1, "write current_images/*.png every N steps (reference: every step); 0 = never"),
-]
+] + REGULARISER_FLAGS
 
 
 def build_parser():
@@ -43,7 +43,7 @@ def main(argv=None):
     steps_done = 0
 
     run.say("Starting optimization...")
-    for epoch in range(args.epochs):
+    for epoch in range(run.progress, args.epochs):
         run.say(f"\nEpoch {epoch}")
         epoch_loss = torch.zeros((), device=run.device)
         for vb in tqdm(list(run.batches()), leave=True, desc="Batch", disable=not run.main):
@@ -71,6 +71,9 @@ def main(argv=None):
                 current=current, content=content, style=style, model=run.vgg, style_weight=args.style_weight,
                 content_weight=args.content_weight, verts=run.opt['verts'], target_verts=run.original_verts, mesh=mesh,
                 weights=run.loss_weights, opt_type=args.optimization_target, batch_denom=vb.size)
+            extra = run.regularisers(current, cov, mesh, vb.hi - vb.lo, vb.size)
+            if torch.is_tensor(extra):              # every weight is 0 by default: nothing is added, as in the reference
+                loss = loss + extra
 
             if args.save_every and steps_done % args.save_every == 0:
                 for j, view in enumerate(current):
@@ -82,6 +85,7 @@ def main(argv=None):
             steps_done += 1
 
         run.log(f'Epoch {epoch}, Loss {run.global_sum(epoch_loss).item()}')
+        run.maybe_checkpoint(epoch + 1)
 
     run.export(run.current_mesh())
 

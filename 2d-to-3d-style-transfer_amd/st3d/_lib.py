@@ -65,6 +65,8 @@ SIGNATURES = {
     "st3d_sqdiff_sum": (c_int, [c_f32p, c_f32p, c_size, c_size, c_float, c_f32p, c_f32p, c_f32p, c_stream]),
     "st3d_axpy_diff": (c_int, [c_f32p, c_f32p, c_size, c_float, c_int, c_f32p, c_stream]),
     "st3d_masked_mse": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_f32p, c_f32p, c_f32p, c_stream]),
+    "st3d_tv_loss": (c_int, [c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_f32p, c_f32p, c_f32p, c_stream]),
+    "st3d_range_loss": (c_int, [c_f32p, c_size, c_f32p, c_f32p, c_f32p, c_stream]),
     "st3d_adam_step": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_size, c_int, c_float, c_float, c_float, c_float, c_stream]),
     "st3d_vgg_create": (c_int, [ctypes.POINTER(ctypes.c_void_p)]),
     "st3d_vgg_set_conv": (c_int, [ctypes.c_void_p, c_int, c_f32p, c_f32p, c_stream]),

@@ -46,6 +46,16 @@ SHARED_FLAGS = [
     # additions; the defaults keep the reference behaviour
     Flag("vgg_weights", str, None, "local VGG-19 state_dict (never downloaded); default ST3D_VGG19_WEIGHTS or seeded weights"),
     Flag("seed", int, None, "seed for camera sampling / noise (the reference is unseeded)"),
+    Flag("verts_lr", float, None, "separate Adam step size for the vertices when both are optimised (notes.txt:29 of the reference)"),
+    Flag("checkpoint_every", int, 0, "write <output_path>/checkpoint.pt (parameters + Adam state) every N epochs/batches; 0 = never"),
+    Flag("resume", str, None, "checkpoint.pt to continue from"),
+]
+
+# regularisers the reference defines but never switches on (losses.py:48-65, notes.txt:36,39); weight 0 = off
+REGULARISER_FLAGS = [
+    Flag("tv_weight", float, 0.0, "weight of the masked total-variation term on the current renders"),
+    Flag("rgb_range_weight", float, 0.0, "weight of the out-of-[0,1] penalty on the texture map"),
+    Flag("texture_l2_weight", float, 0.0, "weight of the squared distance to the original texture map"),
 ]
 
 
@@ -131,7 +141,14 @@ class Run:
 
         # one optimiser (one Adam state) for the whole run, over all view batches
         self.opt = _u.setup_optimizations(args.optimization_target, self.content_mesh, lr)
+        if args.verts_lr is not None and args.optimization_target == 'both':
+            self.opt['optimizer'] = st3d_optim.Adam([{"params": [self.opt['verts']], "lr": args.verts_lr},
+                                                     {"params": [self.opt['texture_map']], "lr": lr}])
         self.optimizer = self.opt['optimizer']
+        self.original_map = tex
+        self.progress = 0               # epochs (second approach) / view batches (first approach) already done
+        if args.resume:
+            self.load_checkpoint(args.resume)
         self.style_image = _u.load_as_tensor(args.style_path, size=args.size)   # loop-invariant; the reference reloads it
         self._log = os.path.join(self.out_dir, 'log.txt')
         if self.main:
@@ -175,6 +192,47 @@ class Run:
         if self.world > 1:
             torch.distributed.all_reduce(t)
         return t
+
+    # ---- checkpoint / resume: parameters + Adam moments + how far the run got
+    def save_checkpoint(self, progress):
+        if not self.main:
+            return
+        blob = {"progress": int(progress), "optimization_target": self.args.optimization_target,
+                "texture_map": self.opt['texture_map'].detach().cpu(), "verts": self.opt['verts'].detach().cpu(),
+                "optimizer": self.optimizer.state_dict()}
+        tmp = os.path.join(self.out_dir, "checkpoint.pt.tmp")
+        torch.save(blob, tmp)
+        os.replace(tmp, os.path.join(self.out_dir, "checkpoint.pt"))
+
+    def load_checkpoint(self, path):
+        blob = torch.load(path, map_location="cpu", weights_only=True)
+        if blob["optimization_target"] != self.args.optimization_target:
+            raise ValueError("checkpoint was written for optimization_target=%r" % blob["optimization_target"])
+        with torch.no_grad():
+            self.opt['texture_map'].copy_(blob["texture_map"])
+            self.opt['verts'].copy_(blob["verts"])
+        self.optimizer.load_state_dict(blob["optimizer"])
+        self.progress = int(blob["progress"])
+        self.say(f"Resumed from {path} at {self.progress}")
+
+    def maybe_checkpoint(self, done):
+        every = self.args.checkpoint_every
+        if every and done % every == 0:
+            self.save_checkpoint(done)
+
+    def regularisers(self, current, coverage, mesh, n_local, batch_size):
+        """Optional extra terms (all weights default to 0 = reference behaviour).  The image term is a per-view mean and
+        is weighted by this rank's share of the batch; the texture terms are view-independent and enter once over all
+        ranks (the gradient all-reduce SUMs)."""
+        import losses as _l
+        a, total = self.args, 0
+        if getattr(a, "tv_weight", 0.0):
+            total = total + a.tv_weight * (n_local / batch_size) * _l.compute_tv_loss(current, coverage)
+        if getattr(a, "rgb_range_weight", 0.0):
+            total = total + (a.rgb_range_weight / self.world) * _l.rgb_range_loss(mesh)
+        if getattr(a, "texture_l2_weight", 0.0):
+            total = total + (a.texture_l2_weight / self.world) * _l.texture_l2_loss(mesh, self.original_map)
+        return total
 
     def export(self, mesh):
         """final_render/view_k.png from 12 turntable cameras + final.obj/.mtl/.png (first_approach.py:219-225)."""

@@ -314,6 +314,27 @@ def masked_mse(rendered, target, mask, want_grad=True):
     return out, g
 
 
+def tv_loss(images, masks, want_grad=True):
+    """masked anisotropic L1 TV / sum(masks) -> (loss (1,), grad_images | None)"""
+    B, C, H, W = images.shape
+    parts = torch.empty((2 * _lib.load().st3d_reduce_partials(),), dtype=F32, device=images.device)
+    out = torch.zeros((2,), dtype=F32, device=images.device)
+    g = torch.empty_like(images, memory_format=torch.contiguous_format) if want_grad else None
+    call("st3d_tv_loss", dptr(images.contiguous(), F32), dptr(masks.contiguous(), F32), B, C, H, W, dptr(parts), dptr(out),
+         dptr(g), stream_ptr())
+    return out[:1], g
+
+
+def range_loss(values, want_grad=True):
+    """sum relu(v - 1) + relu(-v) -> (loss (1,), grad | None)"""
+    v = values.contiguous()
+    parts = torch.empty((_lib.load().st3d_reduce_partials(),), dtype=F32, device=v.device)
+    out = torch.zeros((1,), dtype=F32, device=v.device)
+    g = torch.empty_like(v) if want_grad else None
+    call("st3d_range_loss", dptr(v, F32), v.numel(), dptr(parts), dptr(out), dptr(g), stream_ptr())
+    return out, g
+
+
 def adam_step(p, g, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8):
     call("st3d_adam_step", dptr(p, F32), dptr(g.contiguous(), F32), dptr(m, F32), dptr(v, F32), p.numel(), int(step),
          float(lr), float(b1), float(b2), float(eps), stream_ptr())

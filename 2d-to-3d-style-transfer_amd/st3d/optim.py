@@ -55,12 +55,22 @@ def all_reduce_sum_(t):
 
 
 class Adam:
+    """``Adam(params, lr)`` as the reference uses it, or ``Adam([{"params": [...], "lr": ...}, ...])`` for one
+    learning rate per tensor group (the reference's notes.txt:29 idea; torch.optim's param_groups convention).
+    ``state_dict()`` / ``load_state_dict()`` carry step counts and both moment buffers for checkpoint / resume."""
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, reduce_grads=True):
-        self.params = [p for p in params]
-        self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
+        params = list(params)
+        self.betas, self.eps = (float(betas[0]), float(betas[1])), float(eps)
+        if params and isinstance(params[0], dict):
+            self.param_groups = [{"params": list(g["params"]), "lr": float(g.get("lr", lr)), "betas": self.betas,
+                                  "eps": self.eps} for g in params]
+        else:
+            self.param_groups = [{"params": params, "lr": float(lr), "betas": self.betas, "eps": self.eps}]
+        self.params = [p for g in self.param_groups for p in g["params"]]
+        self.lr = self.param_groups[0]["lr"]
         self.state = {}
         self.reduce_grads = reduce_grads
-        self.param_groups = [{"params": self.params, "lr": self.lr, "betas": self.betas, "eps": self.eps}]
 
     def zero_grad(self, set_to_none=True):
         for p in self.params:
@@ -70,22 +80,45 @@ class Adam:
                 else:
                     p.grad.zero_()
 
+    def _state_of(self, p):
+        st = self.state.get(id(p))
+        if st is None:
+            st = {"step": 0, "exp_avg": torch.zeros_like(p, memory_format=torch.contiguous_format),
+                  "exp_avg_sq": torch.zeros_like(p, memory_format=torch.contiguous_format)}
+            self.state[id(p)] = st
+        return st
+
     @torch.no_grad()
     def step(self):
-        lr = self.param_groups[0]["lr"]
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                g = p.grad.contiguous()
+                if self.reduce_grads:
+                    all_reduce_sum_(g)
+                st = self._state_of(p)
+                st["step"] += 1
+                if not p.is_contiguous():
+                    raise RuntimeError("st3d Adam needs contiguous parameters")
+                ops.adam_step(p.data, g, st["exp_avg"], st["exp_avg_sq"], st["step"], group["lr"], self.betas[0],
+                              self.betas[1], self.eps)
+
+    def state_dict(self):
+        """Positional (like torch.optim): entry k belongs to the k-th parameter in construction order."""
+        out = []
         for p in self.params:
-            if p.grad is None:
-                continue
-            g = p.grad.contiguous()
-            if self.reduce_grads:
-                all_reduce_sum_(g)
-            st = self.state.get(id(p))
-            if st is None:
-                st = {"step": 0, "exp_avg": torch.zeros_like(p, memory_format=torch.contiguous_format),
-                      "exp_avg_sq": torch.zeros_like(p, memory_format=torch.contiguous_format)}
-                self.state[id(p)] = st
-            st["step"] += 1
-            if not p.is_contiguous():
-                raise RuntimeError("st3d Adam needs contiguous parameters")
-            ops.adam_step(p.data, g, st["exp_avg"], st["exp_avg_sq"], st["step"], lr, self.betas[0], self.betas[1],
-                          self.eps)
+            st = self._state_of(p)
+            out.append({"step": st["step"], "exp_avg": st["exp_avg"].detach().cpu(), "exp_avg_sq": st["exp_avg_sq"].detach().cpu()})
+        return {"state": out, "lrs": [g["lr"] for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        if len(sd["state"]) != len(self.params):
+            raise ValueError("optimizer state holds %d tensors, this optimizer has %d" % (len(sd["state"]), len(self.params)))
+        for p, e in zip(self.params, sd["state"]):
+            if tuple(e["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError("optimizer state shape %s does not match parameter %s" % (tuple(e["exp_avg"].shape), tuple(p.shape)))
+            st = self._state_of(p)
+            st["step"] = int(e["step"])
+            st["exp_avg"].copy_(e["exp_avg"])
+            st["exp_avg_sq"].copy_(e["exp_avg_sq"])

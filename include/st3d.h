@@ -189,6 +189,14 @@ int st3d_axpy_diff(const float *a, const float *b, size_t n, float coef, int acc
  * B*3*S*S; grad_r = 2*m*m*(r - t)/(B*3*S*S) (may be NULL). */
 int st3d_masked_mse(const float *rendered, const float *target, const float *mask, int B, int S,
                     float *grad_rendered, float *partials, float *loss_out, st3d_stream_t stream);
+/* masked anisotropic L1 total variation of losses.py:55-65 (compute_tv_loss; every call site in the reference is
+ * commented out): images (B,C,H,W), masks (B,1,H,W); loss_and_mask_sum[0] = (sum |dI/dy| m m' + sum |dI/dx| m m') /
+ * sum(masks), [1] = sum(masks); grad_images (same shape, may be NULL) = d loss / d images.  partials must hold
+ * 2 * st3d_reduce_partials() floats. */
+int st3d_tv_loss(const float *images, const float *masks, int B, int C, int H, int W, float *partials,
+                 float *loss_and_mask_sum, float *grad_images, st3d_stream_t stream);
+/* losses.py:48-51 (rgb_range_loss): loss_out[0] = sum relu(v - 1) + relu(-v); grad (may be NULL) = +1 / -1 / 0 */
+int st3d_range_loss(const float *values, size_t n, float *partials, float *loss_out, float *grad, st3d_stream_t stream);
 
 /* ------------------------------------------------------------------ mesh regularisers:
  * losses.py:84-87,93-96,112-115,121-124 -- F.mse_loss(verts, target), pytorch3d.loss

@@ -450,3 +450,84 @@ def test_soft_renderer_settings_match_oracle_through_the_api(mods, cow):
     bgt = torch.tensor(bg, device=dev).view(1, 3, 1, 1)
     np.testing.assert_allclose(s_rgb.cpu().numpy(), (h_rgb * h_mask + bgt * (1 - h_mask)).cpu().numpy(), atol=2e-6)
     assert torch.equal(s_cov > 0, h_mask > 0)
+
+
+def test_fused_regularisers_match_reference_goldens_and_autograd(mods, golden_dir):
+    """compute_tv_loss / rgb_range_loss (reference losses.py:48-65) and the L2-to-original-texture term on the HIP path:
+    values against the reference's own outputs (G3), gradients against torch autograd of the CPU restatement."""
+    _, L, _, dev = mods
+    from oracle import perceptual_ref as P
+    d = np.load(os.path.join(golden_dir, "g3_perceptual.npz"))
+    cur = torch.from_numpy(d["cur"]).to(dev).requires_grad_(True)
+    masks = torch.from_numpy(d["masks"]).to(dev)
+    tv = L.compute_tv_loss(cur, masks)
+    assert abs(float(tv) - float(d["tv_loss"])) <= 2e-6
+    (tv * 1.7).backward()
+    cr = torch.from_numpy(d["cur"]).double().requires_grad_(True)
+    (P.tv_loss_ref(cr, torch.from_numpy(d["masks"]).double()) * 1.7).backward()
+    np.testing.assert_allclose(cur.grad.cpu().numpy(), cr.grad.numpy(), atol=1e-8, rtol=1e-5)
+
+    tex = (torch.from_numpy(d["cur"]) * 3 - 1).permute(0, 2, 3, 1).contiguous()
+
+    class M:
+        class textures:
+            t = tex.to(dev).requires_grad_(True)
+
+            @staticmethod
+            def maps_padded():
+                return M.textures.t
+    rl = L.rgb_range_loss(M)
+    assert abs(float(rl) - float(d["rgb_range"])) <= 1e-2
+    rl.backward()
+    tr = tex.double().requires_grad_(True)
+    P.rgb_range_loss_ref(tr).backward()
+    assert torch.equal(M.textures.t.grad.cpu().double(), tr.grad)
+
+    M.textures.t.grad = None
+    orig = torch.rand(tex.shape, generator=torch.Generator().manual_seed(5))
+    l2 = L.texture_l2_loss(M, orig.to(dev))
+    ref = ((tex.double() - orig.double()) ** 2).mean()
+    assert abs(float(l2) - float(ref)) <= 1e-6 * float(ref)
+    l2.backward()
+    np.testing.assert_allclose(M.textures.t.grad.cpu().numpy(), (2 * (tex - orig) / tex.numel()).numpy(), rtol=1e-5, atol=1e-10)
+    # odd sizes, all-zero mask rows, non-square images
+    g = torch.Generator().manual_seed(9)
+    img = torch.rand(1, 3, 7, 13, generator=g)
+    m = (torch.rand(1, 1, 7, 13, generator=g) > 0.4).float()
+    x = img.to(dev).requires_grad_(True)
+    t2 = L.compute_tv_loss(x, m.to(dev))
+    xr = img.double().requires_grad_(True)
+    r2 = P.tv_loss_ref(xr, m.double())
+    assert abs(float(t2) - float(r2)) <= 1e-6
+    t2.backward(); r2.backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), xr.grad.numpy(), atol=1e-7)
+
+
+def test_second_approach_checkpoint_resume_and_optional_regularisers(mods, cow, golden_dir, tmp_path):
+    """Additions behind default-off flags: TV / RGB-range / L2-to-original regularisers, a separate vertex learning
+    rate, and checkpoint -> resume.  A run of 2 epochs + resume for 2 more must land where an uninterrupted 4-epoch run
+    lands (same seed, deterministic cameras; float atomics in the texture scatter allow a small tolerance)."""
+    import second_approach as SA
+    obj, style = _write_cow_assets(str(tmp_path), cow, golden_dir)
+    common = ["--obj_path", obj, "--style_path", style, "--size", "64", "--n_views", "2", "--batch_size", "2", "--seed", "0",
+              "--lr", "0.02", "--optimization_target", "both", "--verts_lr", "0.0005", "--tv_weight", "0.3",
+              "--rgb_range_weight", "0.01", "--texture_l2_weight", "5.0", "--save_every", "0"]
+    full, part = str(tmp_path / "full"), str(tmp_path / "part")
+    SA.main(common + ["--epochs", "4", "--output_path", full])
+    SA.main(common + ["--epochs", "2", "--output_path", part, "--checkpoint_every", "1"])
+    ck = os.path.join(part, "checkpoint.pt")
+    blob = torch.load(ck, map_location="cpu", weights_only=True)
+    assert blob["progress"] == 2 and blob["optimization_target"] == "both" and len(blob["optimizer"]["state"]) == 2
+    assert blob["optimizer"]["lrs"] == [0.0005, 0.02]
+    SA.main(common + ["--epochs", "4", "--output_path", part, "--resume", ck])
+    lf = [float(l.split("Loss ")[1]) for l in open(os.path.join(full, "log.txt")).read().splitlines()[1:]]
+    lp = [float(l.split("Loss ")[1]) for l in open(os.path.join(part, "log.txt")).read().splitlines()[1:]]
+    assert len(lf) == 4 and len(lp) == 2            # the resumed run logs epochs 2 and 3 into a fresh log
+    np.testing.assert_allclose(lp, lf[2:], rtol=2e-3)
+    from PIL import Image
+    a = np.asarray(Image.open(os.path.join(full, "final.png")), dtype=np.int32)
+    b = np.asarray(Image.open(os.path.join(part, "final.png")), dtype=np.int32)
+    assert np.abs(a - b).max() <= 2
+    with pytest.raises(ValueError):
+        SA.main(["--obj_path", obj, "--style_path", style, "--size", "64", "--n_views", "2", "--batch_size", "2", "--epochs", "1",
+                 "--output_path", str(tmp_path / "bad"), "--resume", ck])          # texture-only run, 'both' checkpoint
