@@ -322,7 +322,10 @@ def test_mesh_regularisers_match_oracle(dev, ops, cow):
 
 # ---------------------------------------------------------------------------- Winograd F(2x2,3x3) conv
 WINO_CASES = [(2, 64, 64, 64, 64), (1, 64, 128, 32, 32), (1, 128, 256, 24, 56), (1, 256, 256, 32, 32), (2, 512, 512, 16, 16),
-              (1, 512, 512, 4, 4), (1, 64, 64, 48, 40), (1, 128, 64, 10, 12)]
+              (1, 512, 512, 4, 4), (1, 64, 64, 48, 40), (1, 128, 64, 10, 12),
+              # more workgroup tiles than CUs: the persistent workgroups walk several tiles (cross-tile prefetch, image
+              # change between consecutive tiles, uneven tile counts per workgroup)
+              (3, 64, 64, 256, 128), (2, 64, 128, 192, 160), (1, 128, 128, 256, 256)]
 
 
 @pytest.mark.parametrize("N,Cin,Cout,H,W", WINO_CASES)
@@ -342,13 +345,19 @@ def test_wino_fwd_dgrad(dev, ops, N, Cin, Cout, H, W):
     y_nr = ops.wino_fwd(x.detach().float().to(dev), uf, b.float().to(dev), Cout, relu=False)
     _scale_close(y_nr, F.conv2d(x.detach(), w, b, padding=1), 3e-5, "wino fwd (no relu)")
     gx = ops.wino_dgrad(gy.float().to(dev), yd, ud, Cin)
-    _scale_close(gx, x.grad, 5e-5, "wino dgrad")
+    # reference gradient through the SAME gate the kernel saw (the GPU's own activation): an output within rounding
+    # of 0 may sit on the other side of the ReLU in fp64, and with millions of outputs some do
+    gate = (yd.cpu() > 0).double()
+    assert float((gate - (y.detach() > 0).double()).abs().mean()) < 1e-5
+    ref_gx = torch.autograd.grad(F.conv2d(x, w, b, padding=1), x, gy * gate)[0]
+    _scale_close(gx, ref_gx, 5e-5, "wino dgrad")
     # agreement with the direct MFMA kernel (different algorithm, same inputs)
     wf, wd = ops.conv3x3_pack(w.float().to(dev))
     _scale_close(yd, ops.conv3x3_fwd(x.detach().float().to(dev), wf, b.float().to(dev), Cout, relu=True), 3e-5, "wino vs direct")
 
 
-@pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 64, 64, 32, 64), (1, 128, 128, 16, 16), (1, 256, 256, 8, 40)])
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 64, 64, 32, 64), (1, 128, 128, 16, 16), (1, 256, 256, 8, 40),
+                                             (3, 64, 64, 256, 128), (2, 128, 64, 160, 192)])
 def test_wino_fused_pool_and_unpool(dev, ops, N, Cin, Cout, H, W):
     """conv -> ReLU -> MaxPool2d(2,2) fused in the Winograd epilogue (values + ATen's first-max argmax),
     and the gradient back through pool + ReLU + conv in one kernel."""
@@ -359,7 +368,6 @@ def test_wino_fused_pool_and_unpool(dev, ops, N, Cin, Cout, H, W):
     y = F.relu(F.conv2d(x, w, b, padding=1))
     p = F.max_pool2d(y, 2, 2)
     gp = torch.randn_like(p)
-    p.backward(gp)
     uf, ud = ops.wino_pack(w.float().to(dev))
     yd, pd, idx = ops.wino_fwd(x.detach().float().to(dev), uf, b.float().to(dev), Cout, relu=True, pool=True)
     _scale_close(yd, y, 3e-5, "wino fwd")
@@ -369,7 +377,16 @@ def test_wino_fused_pool_and_unpool(dev, ops, N, Cin, Cout, H, W):
                                         keep_full=False)
     assert none_full is None and torch.equal(pd3, pd) and torch.equal(idx3, idx)
     gx = ops.wino_dgrad_unpool(gp.float().to(dev), idx, pd, ud, Cin)
-    _scale_close(gx, x.grad, 6e-5, "wino dgrad_unpool")
+    # reference through the SAME argmax / gate the kernel saw (near-ties inside a window and outputs within rounding of
+    # 0 can resolve differently in fp64; with millions of windows some do)
+    ic = idx.cpu().long()
+    up = torch.zeros_like(y)
+    gated = gp * (pd.cpu() > 0).double()
+    for k in range(4):
+        up[:, :, (k >> 1)::2, (k & 1)::2] = gated * (ic == k).double()
+    assert float((up != 0).double().mean() - (torch.autograd.grad(p, y, gp, retain_graph=True)[0] != 0).double().mean()) < 1e-4
+    ref_gx = torch.autograd.grad(F.conv2d(x, w, b, padding=1), x, up)[0]
+    _scale_close(gx, ref_gx, 6e-5, "wino dgrad_unpool")
 
 
 # ---------------------------------------------------------------------------- general soft renderer (K faces / pixel, blur)
