@@ -169,7 +169,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
 
 // G[b][i][j] = sum over the split slabs of the element, in a FIXED tree (4 interleaved partial sums per element, each
 // over its slabs in ascending order, then ((p0+p1)+(p2+p3))) -- bitwise reproducible, and four times the loads in
-// flight of a single running sum.  Tiles below the diagonal are read transposed from the mirrored tile.
+// flight of a single running sum.  Only tiles on/above the diagonal are read (coalesced); each such element is also
+// written to its mirror position, so the Gram is exactly symmetric.
 __global__ __launch_bounds__(256) void gram_reduce_kernel(const float *__restrict__ slab, int nsplit, int C, int TM,
                                                           size_t sSplit, size_t sB, float *__restrict__ gram) {
     __shared__ float part[4][64];
@@ -178,9 +179,9 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const float *__restric
     const size_t CC = (size_t)C * C;
     const int b = blockIdx.y;
     float s = 0.f;
-    if (i < CC) {
-        int r = i / C, c = i % C;
-        if (r / TM > c / TM) { const int t = r; r = c; c = t; }
+    const int r = (i < CC) ? (int)(i / C) : 0, c = (i < CC) ? (int)(i % C) : 0;
+    const bool lower = r / TM > c / TM;         // tile below the diagonal: written by its mirror image's threads
+    if (i < CC && !lower) {
         const float *p = slab + b * sB + (size_t)r * C + c;
         int k = q;
         for (; k + 12 < nsplit; k += 16) {
@@ -191,7 +192,11 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const float *__restric
     }
     part[q][e] = s;
     __syncthreads();
-    if (q == 0 && i < CC) gram[b * CC + i] = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+    if (q == 0 && i < CC && !lower) {
+        const float v = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+        gram[b * CC + i] = v;
+        if (r / TM < c / TM) gram[b * CC + (size_t)c * C + r] = v;       // the mirrored (never computed) tile
+    }
 }
 
 // K split: enough workgroups to fill the chip twice over (256 CUs x 2 resident workgroups x 2), but
