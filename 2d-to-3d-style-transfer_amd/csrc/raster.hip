@@ -6,23 +6,27 @@
 // Layout / kernels (all B views of a batch in one launch each):
 //   project_verts_kernel   (B*V threads)   world -> (x_ndc, y_ndc, z_view)
 //   face_setup_kernel      (B*F threads)   gathers the 3 projected vertices of every face into a
-//                                          48-byte record (3 x float4) so the tile kernel streams
-//                                          faces with coalesced 16-B loads instead of 9 gathers
+//                                          48-byte record (3 x float4) and packs the 16-pixel tiles its
+//                                          bounding box can touch into one 32-bit word
 //   raster_tile_kernel     one 256-thread workgroup per 16x16 pixel tile: the four waves sweep
-//                          the face list 256 faces at a time, bbox-test them against the tile
-//                          (wave ballots -> ordered compaction), stage the surviving faces'
-//                          records in LDS, then every lane (= pixel) walks the LDS list
+//                          the packed tile ranges 512 faces at a time (4 B per face, not the record),
+//                          compact the hits in face order (wave ballots), fetch only the hits'
+//                          records into LDS, then every lane (= pixel) walks the LDS list
 //                          (same-address broadcast reads, no bank conflicts).
-// HBM-bound by construction: algorithmic bytes per view = F*48 (records, re-read once per tile
-// from L2) + S*S*24 written.  Built with -ffp-contract=off so the arithmetic is the same
-// operation sequence as oracle/raster_ref.c (bit-comparable).
+// Measured at config 2 (8 views, 512^2, cow): 0.20 ms, of which 0.055 ms is the sweep (mesh pushed off
+// screen); the rest is the per-pixel walk, bounded by the densest tiles (up to 330 one-pixel faces per
+// tile, 50 on average over the 32 % non-empty tiles).  Variants that did NOT help and were dropped
+// (tools/shade_bench.py): 1024 faces per pass (40 KB of LDS), prefetching records, bbox/area staged in
+// LDS with a sign early-out before the six divisions, one 8x8 quadrant per wave with wave-level culling.
+// Algorithmic bytes per view = F*52 + S*S*24 written.  Built with -ffp-contract=off so the arithmetic
+// is the same operation sequence as oracle/raster_ref.c (bit-comparable).
 #include "common.h"
 
 namespace {
 
 constexpr float kEps = 1e-8f;
 constexpr int TILE = 16;       // 16x16 pixels per workgroup
-constexpr int LIST_CAP = 512;  // faces staged in LDS per flush
+constexpr int LIST_CAP = 512;  // faces swept (and at most staged in LDS) per pass
 
 __device__ __forceinline__ float pix_to_ndc(int i, int S) { return -1.0f + (2.0f * (float)i + 1.0f) / (float)S; }
 
@@ -60,11 +64,26 @@ __global__ void project_verts_kernel(const float *__restrict__ verts, int V, con
 }
 
 // record: [x0 y0 z0 x1][y1 z1 x2 y2][z2 valid 0 0]
+// words (optional, one per face, view stride Fp = F rounded up to 2): the 16-pixel tiles the face's bounding box can
+// touch, packed tx0 | tx1<<8 | ty0<<16 | ty1<<24 -- a conservative superset (one pixel of slack each side; the exact
+// bbox test is repeated per pixel).  The tile kernel sweeps these 4 bytes per face instead of the 48-byte record
+// (every tile reads every face: 8192 tiles x 5856 faces x 48 B = 2.3 GB of L2 reads per 8-view batch before, 0.19 GB now).
+constexpr unsigned kEmptyRange = 1u;     // tx0 = 1 > tx1 = 0
+
+__device__ __forceinline__ void pixel_span(float cmin, float cmax, int S, int &lo, int &hi) {
+    // pixel index i has NDC centre 1 - (2i+1)/S  <=>  i = ((1 - c) * S - 1) / 2
+    const float a = fminf(fmaxf(((1.0f - cmax) * (float)S - 1.0f) * 0.5f, -4.0f), (float)S + 4.0f);
+    const float b = fminf(fmaxf(((1.0f - cmin) * (float)S - 1.0f) * 0.5f, -4.0f), (float)S + 4.0f);
+    lo = (int)floorf(a) - 1; hi = (int)ceilf(b) + 1;
+}
+
 __global__ void face_setup_kernel(const float *__restrict__ ndc, const int32_t *__restrict__ faces, int B, int V, int F,
-                                  float4 *__restrict__ rec) {
+                                  float4 *__restrict__ rec, int S, int Fp, unsigned *__restrict__ words) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * F) return;
-    const int b = i / F, f = i - b * F;
+    const int stride = words ? Fp : F;
+    if (i >= B * stride) return;
+    const int b = i / stride, f = i - b * stride;
+    if (f >= F) { words[i] = kEmptyRange; return; }
     const float *vb = ndc + (size_t)b * V * 3;
     const int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
     const float x0 = vb[3 * i0], y0 = vb[3 * i0 + 1], z0 = vb[3 * i0 + 2];
@@ -73,9 +92,24 @@ __global__ void face_setup_kernel(const float *__restrict__ ndc, const int32_t *
     const float zmax = fmaxf(z0, fmaxf(z1, z2));
     const float area = edge_fn(x2, y2, x0, y0, x1, y1);
     const bool valid = !(zmax < kEps) && !(area <= kEps && area >= -kEps);
-    rec[3 * (size_t)i + 0] = make_float4(x0, y0, z0, x1);
-    rec[3 * (size_t)i + 1] = make_float4(y1, z1, x2, y2);
-    rec[3 * (size_t)i + 2] = make_float4(z2, valid ? 1.f : 0.f, 0.f, 0.f);
+    const size_t o = (size_t)b * F + f;
+    rec[3 * o + 0] = make_float4(x0, y0, z0, x1);
+    rec[3 * o + 1] = make_float4(y1, z1, x2, y2);
+    rec[3 * o + 2] = make_float4(z2, valid ? 1.f : 0.f, 0.f, 0.f);
+    if (words) {
+        unsigned w = kEmptyRange;
+        if (valid) {
+            int xlo, xhi, ylo, yhi;
+            pixel_span(fminf(x0, fminf(x1, x2)), fmaxf(x0, fmaxf(x1, x2)), S, xlo, xhi);
+            pixel_span(fminf(y0, fminf(y1, y2)), fmaxf(y0, fmaxf(y1, y2)), S, ylo, yhi);
+            if (xhi >= 0 && yhi >= 0 && xlo <= S - 1 && ylo <= S - 1) {
+                xlo = max(xlo, 0); ylo = max(ylo, 0); xhi = min(xhi, S - 1); yhi = min(yhi, S - 1);
+                w = (unsigned)(xlo / TILE) | ((unsigned)(xhi / TILE) << 8) | ((unsigned)(ylo / TILE) << 16) |
+                    ((unsigned)(yhi / TILE) << 24);
+            }
+        }
+        words[i] = w;
+    }
 }
 
 struct Best {
@@ -105,9 +139,10 @@ __device__ __forceinline__ void eval_face(int f, float x0, float y0, float z0, f
     }
 }
 
-__global__ __launch_bounds__(256) void raster_tile_kernel(const float4 *__restrict__ rec, int F, int S,
-                                                          int32_t *__restrict__ pix_to_face, float *__restrict__ zbuf,
-                                                          float *__restrict__ bary, float *__restrict__ dists) {
+__global__ __launch_bounds__(256) void raster_tile_kernel(const float4 *__restrict__ rec, const unsigned *__restrict__ words,
+                                                          int F, int Fp, int S, int32_t *__restrict__ pix_to_face,
+                                                          float *__restrict__ zbuf, float *__restrict__ bary,
+                                                          float *__restrict__ dists) {
     __shared__ float s_face[LIST_CAP][9];
     __shared__ int s_fidx[LIST_CAP];
     __shared__ int s_wcnt[4];
@@ -120,50 +155,57 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const float4 *__restri
     const bool in_img = px < S && py < S;
     const float xf = pix_to_ndc(S - 1 - px, S);
     const float yf = pix_to_ndc(S - 1 - py, S);
-    // tile extent in NDC (pixel centres); +x / +y point left / up so the min pixel index is the max coord
-    const int px_hi = min(blockIdx.x * TILE + TILE - 1, S - 1), py_hi = min(blockIdx.y * TILE + TILE - 1, S - 1);
-    const float tx_max = pix_to_ndc(S - 1 - blockIdx.x * TILE, S), tx_min = pix_to_ndc(S - 1 - px_hi, S);
-    const float ty_max = pix_to_ndc(S - 1 - blockIdx.y * TILE, S), ty_min = pix_to_ndc(S - 1 - py_hi, S);
-
     const float4 *rb = rec + (size_t)b * F * 3;
+    const uint2 *wb = reinterpret_cast<const uint2 *>(words + (size_t)b * Fp);
+    const unsigned bx = blockIdx.x, by = blockIdx.y;
     Best best;
     best.f = -1; best.z = 0.f; best.b0 = best.b1 = best.b2 = 0.f;
-    int count = 0;
 
-    for (int base = 0; base < F; base += 256) {
-        const int f = base + tid;
-        bool hit = false;
-        float4 r0, r1, r2;
-        if (f < F) {
-            r0 = rb[3 * (size_t)f]; r1 = rb[3 * (size_t)f + 1]; r2 = rb[3 * (size_t)f + 2];
-            const float xmin = fminf(r0.x, fminf(r0.w, r1.z)), xmax = fmaxf(r0.x, fmaxf(r0.w, r1.z));
-            const float ymin = fminf(r0.y, fminf(r1.x, r1.w)), ymax = fmaxf(r0.y, fmaxf(r1.x, r1.w));
-            hit = (r2.y != 0.f) && !(tx_min > xmax || tx_max < xmin || ty_min > ymax || ty_max < ymin);
+    // sweep the packed tile ranges LIST_CAP = 512 faces per pass (2 consecutive faces per lane, one 8-byte load, the next
+    // pass's words prefetched), compact the hits in face order (ties in depth keep the smaller index), fetch only the
+    // hits' records into LDS, evaluate, repeat
+    uint2 wn = make_uint2(kEmptyRange, kEmptyRange);
+    if (2 * tid < Fp) wn = wb[tid];
+    for (int base = 0; base < Fp; base += LIST_CAP) {
+        const int f0 = base + 2 * tid;
+        const uint2 w2 = wn;
+        wn = make_uint2(kEmptyRange, kEmptyRange);
+        if (f0 + LIST_CAP < Fp) wn = wb[(f0 + LIST_CAP) >> 1];
+        const unsigned wv[2] = {w2.x, w2.y};
+        bool hit[2];
+        int before = 0, wave_total = 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const unsigned w = wv[j];
+            hit[j] = (w & 255u) <= bx && bx <= ((w >> 8) & 255u) && ((w >> 16) & 255u) <= by && by <= (w >> 24);
+            const unsigned long long m = __ballot(hit[j]);
+            before += __popcll(m & ((1ull << lane) - 1ull));
+            wave_total += __popcll(m);
         }
-        const unsigned long long m = __ballot(hit);
-        if (lane == 0) s_wcnt[wave] = __popcll(m);
+        if (lane == 0) s_wcnt[wave] = wave_total;
         __syncthreads();
-        int off = count;
+        int off = 0;
         for (int w = 0; w < wave; ++w) off += s_wcnt[w];
-        const int total = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
-        if (hit) {
-            const int slot = off + __popcll(m & ((1ull << lane) - 1ull));
-            s_fidx[slot] = f;
-            s_face[slot][0] = r0.x; s_face[slot][1] = r0.y; s_face[slot][2] = r0.z;
-            s_face[slot][3] = r0.w; s_face[slot][4] = r1.x; s_face[slot][5] = r1.y;
-            s_face[slot][6] = r1.z; s_face[slot][7] = r1.w; s_face[slot][8] = r2.x;
-        }
-        count += total;
-        __syncthreads();
-        const bool last = base + 256 >= F;
-        if (count > LIST_CAP - 256 || last) {
-            for (int i = 0; i < count; ++i) {
-                eval_face(s_fidx[i], s_face[i][0], s_face[i][1], s_face[i][2], s_face[i][3], s_face[i][4], s_face[i][5],
-                          s_face[i][6], s_face[i][7], s_face[i][8], xf, yf, best);
+        const int count = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+        int mine = 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (hit[j]) {
+                const int f = f0 + j, slot = off + before + mine;
+                const float4 r0 = rb[3 * (size_t)f], r1 = rb[3 * (size_t)f + 1], r2 = rb[3 * (size_t)f + 2];
+                s_fidx[slot] = f;
+                s_face[slot][0] = r0.x; s_face[slot][1] = r0.y; s_face[slot][2] = r0.z;
+                s_face[slot][3] = r0.w; s_face[slot][4] = r1.x; s_face[slot][5] = r1.y;
+                s_face[slot][6] = r1.z; s_face[slot][7] = r1.w; s_face[slot][8] = r2.x;
+                ++mine;
             }
-            count = 0;
-            __syncthreads();
         }
+        __syncthreads();
+        for (int i = 0; i < count; ++i) {
+            eval_face(s_fidx[i], s_face[i][0], s_face[i][1], s_face[i][2], s_face[i][3], s_face[i][4], s_face[i][5],
+                      s_face[i][6], s_face[i][7], s_face[i][8], xf, yf, best);
+        }
+        if (count) __syncthreads();          // (count is workgroup-uniform) the list is rewritten by the next pass
     }
     if (!in_img) return;
     const size_t p = ((size_t)b * S + py) * S + px;
@@ -194,15 +236,18 @@ extern "C" int st3d_project_verts(const float *verts, int V, const float *R, con
     return ST3D_OK;
 }
 
-extern "C" size_t st3d_raster_workspace_bytes(int B, int F) { return (size_t)B * (size_t)F * 3 * sizeof(float4); }
+// face records (48 B per face and view) + packed tile ranges (4 B, view stride rounded up to 2 faces)
+extern "C" size_t st3d_raster_workspace_bytes(int B, int F) {
+    return (size_t)B * (size_t)F * 3 * sizeof(float4) + (size_t)B * (size_t)((F + 1) & ~1) * sizeof(unsigned);
+}
 
 extern "C" int st3d_face_setup(const float *verts_ndc, const int32_t *faces, int B, int V, int F, void *face_records,
                                size_t records_bytes, st3d_stream_t stream) {
     ST3D_CHECK_ARG(verts_ndc && faces && face_records);
     ST3D_CHECK_ARG(B > 0 && V > 0 && F > 0 && records_bytes >= st3d_raster_workspace_bytes(B, F));
     ST3D_CHECK_ARG(((uintptr_t)face_records & 15) == 0);
-    face_setup_kernel<<<st3d::cdiv((long)B * F, 256), 256, 0, st3d::as_stream(stream)>>>(verts_ndc, faces, B, V, F,
-                                                                                       reinterpret_cast<float4 *>(face_records));
+    face_setup_kernel<<<st3d::cdiv((long)B * F, 256), 256, 0, st3d::as_stream(stream)>>>(
+        verts_ndc, faces, B, V, F, reinterpret_cast<float4 *>(face_records), 0, F, nullptr);
     ST3D_LAUNCH_CHECK();
     return ST3D_OK;
 }
@@ -211,15 +256,17 @@ extern "C" int st3d_raster_fwd(const float *verts_ndc, const int32_t *faces, int
                                size_t workspace_bytes, int32_t *pix_to_face, float *zbuf, float *bary, float *dists,
                                st3d_stream_t stream) {
     ST3D_CHECK_ARG(verts_ndc && faces && workspace && pix_to_face && zbuf && bary && dists);
-    ST3D_CHECK_ARG(B > 0 && V > 0 && F > 0 && S > 0);
+    ST3D_CHECK_ARG(B > 0 && V > 0 && F > 0 && S > 0 && S <= 4096);       // 8-bit tile indices in the packed ranges
     ST3D_CHECK_ARG(workspace_bytes >= st3d_raster_workspace_bytes(B, F));
     ST3D_CHECK_ARG(((uintptr_t)workspace & 15) == 0);
     hipStream_t s = st3d::as_stream(stream);
     float4 *rec = reinterpret_cast<float4 *>(workspace);
-    face_setup_kernel<<<st3d::cdiv((long)B * F, 256), 256, 0, s>>>(verts_ndc, faces, B, V, F, rec);
+    const int Fp = (F + 1) & ~1;
+    unsigned *words = reinterpret_cast<unsigned *>(rec + (size_t)B * F * 3);
+    face_setup_kernel<<<st3d::cdiv((long)B * Fp, 256), 256, 0, s>>>(verts_ndc, faces, B, V, F, rec, S, Fp, words);
     ST3D_LAUNCH_CHECK();
     const int tiles = st3d::cdiv(S, TILE);
-    raster_tile_kernel<<<dim3(tiles, tiles, B), 256, 0, s>>>(rec, F, S, pix_to_face, zbuf, bary, dists);
+    raster_tile_kernel<<<dim3(tiles, tiles, B), 256, 0, s>>>(rec, words, F, Fp, S, pix_to_face, zbuf, bary, dists);
     ST3D_LAUNCH_CHECK();
     return ST3D_OK;
 }

@@ -42,3 +42,9 @@ timed(lambda: ops.shade_bwd(grad, frag, uvs, fuv, tex, want_texture=False, want_
 gb = ops.shade_bwd(grad, frag, uvs, fuv, tex, want_texture=False, want_bary=True)
 gb = gb[-1] if isinstance(gb, tuple) else gb
 timed(lambda: ops.raster_bwd(gb, frag[0], ndc, faces), "raster_bwd")
+# pure sweep cost: the same mesh pushed off screen (no tile is hit)
+ndc_off = ndc.clone(); ndc_off[..., 0] += 50.0
+timed(lambda: ops.raster_fwd(ndc_off, faces, S), "raster_fwd, mesh off screen (sweep only)")
+# tiny mesh: a 10th of the size (few tiles hit, short lists)
+ndc_small = ndc.clone(); ndc_small[..., :2] *= 0.1
+timed(lambda: ops.raster_fwd(ndc_small, faces, S), "raster_fwd, mesh scaled 0.1")
