@@ -50,7 +50,7 @@ int st3d_device_info(int device, int *cu_count, size_t *hbm_bytes, char *name, i
 int st3d_project_verts(const float *verts, int V, const float *R, const float *T, int B,
                        float inv_tan_half_fov, float *verts_ndc, st3d_stream_t stream);
 
-/* bytes of scratch st3d_raster_fwd needs (per-view packed face records) */
+/* bytes of scratch st3d_raster_fwd needs: per-view face records (48 B per face) + packed tile ranges (4 B per face) */
 size_t st3d_raster_workspace_bytes(int B, int F);
 
 /* Hard rasterisation (K=1, blur_radius=0, perspective-correct barycentrics).

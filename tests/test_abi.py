@@ -57,7 +57,8 @@ def test_invalid_arguments_are_reported_not_crashed(lib_path):
     assert rc == -1 and b"invalid argument" in lib.st3d_last_error()
     rc = lib.st3d_conv3x3_fwd(None, None, None, None, 1, 3, 64, 8, 8, 1, None)
     assert rc == -1
-    assert lib.st3d_raster_workspace_bytes(2, 100) == 2 * 100 * 48
+    assert lib.st3d_raster_workspace_bytes(2, 100) == 2 * 100 * 48 + 2 * 100 * 4       # records + packed tile ranges
+    assert lib.st3d_raster_workspace_bytes(1, 7) == 7 * 48 + 8 * 4                     # range words padded to 2 faces
     assert lib.st3d_conv3x3_packed_floats(64, 3) == max(9 * 4 * 128, 9 * 64 * 128)
     assert lib.st3d_reduce_partials() == 1024
 
