@@ -92,7 +92,9 @@ int st3d_project_verts_bwd(const float *verts, int V, const float *R, const floa
                            float inv_tan_half_fov, const float *grad_verts_ndc, int accumulate,
                            float *grad_verts, st3d_stream_t stream);
 
-/* ---- general soft renderer (the reference fixes K = 1, blur = 0 and uses the entry points above):
+/* ---- general soft renderer: PyTorch3D's MeshRasterizer / SoftPhongShader under any other
+ * RasterizationSettings / BlendParams than the ones the reference constructs at first_approach.py:107-113 and
+ * second_approach.py:101-108 (K = 1, blur_radius = 0, default blend, served by the entry points above):
  * K = faces_per_pixel <= 8 nearest faces per pixel, blur_radius >= 0, barycentric clipping (PyTorch3D clips when
  * blur_radius > 0), softmax_rgb_blend over the K layers with sigma / gamma / background (host float[3]).
  * Fragment arrays are (B,S,S,K[,3]), depth-sorted, -1 filled. */
