@@ -551,3 +551,40 @@ def test_third_approach_cli_end_to_end(mods, cow, golden_dir, tmp_path):
     final = np.asarray(Image.open(os.path.join(outp, "final.png")))
     assert final.shape == (64, 64, 3) and tex0.shape[2] == 3          # resized to --size; it must differ from a plain resize
     assert np.abs(final.astype(np.int32) - np.asarray(Image.fromarray(tex0).resize((64, 64))).astype(np.int32)).max() > 3
+
+
+def test_full_size_single_view_loss_and_gradient_match_oracle(mods, vgg, scene, golden_dir):
+    """BASELINE.json configs[1] resolution (512x512, 512^2 texture, the real Style_1 fixture), ONE view so the CPU oracle
+    finishes in seconds: rendered pixels, perceptual loss and d loss / d texture against the torch-CPU restatement of
+    the reference step (the same functions the G3 goldens pin to the reference's own code)."""
+    _, L, U, dev = mods
+    from oracle import perceptual_ref as P
+    from oracle import render_ref as rr
+    S, T = 512, 512
+    mesh0, renderer, cams, tex_np, R, Tt = scene(S, T, 1, seed=3)
+    cow = np.load(os.path.join(golden_dir, "assets_cow_mesh.npz"))
+    sty_u8 = np.load(os.path.join(golden_dir, "assets_style1_512.npz"))["rgb_u8"]
+    style = torch.from_numpy(sty_u8).permute(2, 0, 1).float().div(255.0)[None]
+    out = U.setup_optimizations("texture", mesh0, 0.01)
+    with torch.no_grad():
+        content, _ = U.render_meshes(renderer, mesh0, cams)
+        out["texture_map"].add_(0.05 * torch.randn(out["texture_map"].shape, generator=torch.Generator().manual_seed(1)).to(dev))
+    mesh = U.build_mesh(out["verts_uvs"], out["faces_uvs"], out["texture_map"], out["verts"], out["faces"])
+    cur, _ = U.render_meshes(renderer, mesh, cams)
+    loss = L.compute_perceptual_loss(cur, content, style.to(dev), vgg)
+    loss.backward()
+    # oracle: naive rasteriser + shading, torch-CPU VGG, texture scatter
+    tex_cur = out["texture_map"].detach().cpu().numpy()[0]
+    img0, _, _ = rr.render_views(cow["verts"], cow["faces"], cow["verts_uvs"], cow["faces_uvs"], tex_np, R, Tt, S, 16)
+    img1, _, frags = rr.render_views(cow["verts"], cow["faces"], cow["verts_uvs"], cow["faces_uvs"], tex_cur, R, Tt, S, 16)
+    np.testing.assert_allclose(cur.detach().cpu().numpy(), img1, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(content.cpu().numpy(), img0, rtol=0, atol=2e-6)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    cur_t = torch.from_numpy(img1).requires_grad_(True)
+    ref = P.perceptual_loss_ref(cur_t, torch.from_numpy(img0), style, P.make_vgg19_features(seed=0))
+    ref.backward()
+    assert abs(loss.item() - float(ref)) <= 2e-5 * float(ref), (loss.item(), float(ref))
+    gt_ref = rr.shade_bwd(cur_t.grad.numpy()[0], frags[0], cow["verts_uvs"], cow["faces_uvs"], tex_cur)
+    g = out["texture_map"].grad[0].cpu().double().numpy()
+    rel = np.linalg.norm(g - gt_ref) / np.linalg.norm(gt_ref)
+    assert rel <= 1e-4, rel
