@@ -235,8 +235,14 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float *__restrict__ 
     const int xo = i % Wp, yo = (i / Wp) % Hp;
     const size_t pl = i / ((size_t)Wp * Hp);
     const float *src = y + pl * H * W + (size_t)(2 * yo) * W + 2 * xo;
-    const float2 r0 = *reinterpret_cast<const float2 *>(src);
-    const float2 r1 = *reinterpret_cast<const float2 *>(src + W);
+    float2 r0, r1;
+    if ((W & 1) == 0) {         // rows stay 8-byte aligned
+        r0 = *reinterpret_cast<const float2 *>(src);
+        r1 = *reinterpret_cast<const float2 *>(src + W);
+    } else {                    // odd width (floor pooling drops the last column, like MaxPool2d)
+        r0 = make_float2(src[0], src[1]);
+        r1 = make_float2(src[W], src[W + 1]);
+    }
     // ATen max_pool2d scans the window row-major and keeps the first maximum (NaN propagates)
     float best = r0.x; int bi = 0;
     if (r0.y > best || r0.y != r0.y) { best = r0.y; bi = 1; }
@@ -525,7 +531,7 @@ extern "C" int st3d_conv3x3_dgrad_unpool(const float *gy_pooled, const uint8_t *
 
 extern "C" int st3d_maxpool2x2_fwd(const float *y, float *p, uint8_t *idx, int N, int C, int H, int W, st3d_stream_t stream) {
     ST3D_CHECK_ARG(y && p);
-    ST3D_CHECK_ARG(N > 0 && C > 0 && H > 1 && W > 1 && (W % 2) == 0);
+    ST3D_CHECK_ARG(N > 0 && C > 0 && H > 1 && W > 1);
     const size_t n = (size_t)N * C * (H / 2) * (W / 2);
     maxpool_kernel<<<st3d::cdiv((long)n, 256), 256, 0, st3d::as_stream(stream)>>>(y, p, idx, (size_t)N * C, H, W);
     ST3D_LAUNCH_CHECK();

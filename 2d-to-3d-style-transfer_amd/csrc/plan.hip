@@ -236,7 +236,7 @@ int forward(st3d_plan *p, const float *imgs, int n, int upto, bool keep_full, hi
 
 extern "C" int st3d_plan_create(st3d_plan **out, st3d_vgg *vgg, int B, int S) {
     ST3D_CHECK_ARG(out && vgg);
-    ST3D_CHECK_ARG(B > 0 && S >= 32 && (S % 32) == 0);
+    ST3D_CHECK_ARG(B > 0 && S >= 16);      // any size: shapes the Winograd kernels do not cover (odd H, W % 4) run on the direct ones, pools floor like MaxPool2d
     st3d_plan *p = new st3d_plan();
     p->vgg = vgg; p->B = B; p->S = S; p->bytes = 0;
     for (int m = 0; m < kModules; ++m) { p->act[m] = nullptr; p->C[m] = p->H[m] = p->W[m] = 0; }

@@ -231,6 +231,8 @@ int st3d_vgg_set_conv(st3d_vgg *vgg, int module_idx, const float *w, const float
                       st3d_stream_t stream);
 int st3d_vgg_destroy(st3d_vgg *vgg);
 
+/* workspace for batches of up to B images of S x S (any S >= 16; sizes off the fast path -- odd intermediate
+ * resolutions, W % 4 != 0 -- run on the direct conv / separate pool kernels, pools floor like MaxPool2d) */
 int st3d_plan_create(st3d_plan **out, st3d_vgg *vgg, int B, int S);
 int st3d_plan_destroy(st3d_plan *plan);
 size_t st3d_plan_bytes(const st3d_plan *plan);

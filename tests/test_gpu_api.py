@@ -588,3 +588,36 @@ def test_full_size_single_view_loss_and_gradient_match_oracle(mods, vgg, scene, 
     g = out["texture_map"].grad[0].cpu().double().numpy()
     rel = np.linalg.norm(g - gt_ref) / np.linalg.norm(gt_ref)
     assert rel <= 1e-4, rel
+
+
+@pytest.mark.parametrize("S,B", [(90, 2), (100, 1), (34, 1)])
+def test_sizes_off_the_fast_path_match_oracle(mods, vgg, S, B):
+    """Image sizes that are not multiples of 16 (the reference accepts any --size): odd intermediate resolutions fall off
+    the Winograd / fused-pool kernels onto the direct ones, MaxPool2d floors.  Loss and gradient vs the CPU oracle."""
+    ST, L, _, dev = mods
+    from oracle import perceptual_ref as P
+    g = torch.Generator().manual_seed(S)
+    cur, con = torch.rand(B, 3, S, S, generator=g), torch.rand(B, 3, S, S, generator=g)
+    sty = torch.rand(1, 3, S, S, generator=g).repeat(B, 1, 1, 1)
+    x = cur.clone().to(dev).requires_grad_(True)
+    loss = L.compute_perceptual_loss(x, con.to(dev), sty.to(dev), vgg)
+    loss.backward()
+    xr = cur.clone().requires_grad_(True)
+    model = P.make_vgg19_features(seed=0)
+    ref = P.perceptual_loss_ref(xr, con, sty, model)
+    ref.backward()
+    assert abs(loss.item() - float(ref.detach())) <= 2e-5 * float(ref.detach())
+    assert float((x.grad.cpu() - xr.grad).norm() / xr.grad.norm()) <= 1e-4
+    # every tap incl. the unused tail (module 36 = pool5) at these sizes
+    feats = ST.get_features(cur.to(dev), vgg, layers={"4": "pool1", "28": "conv5_1", "36": "pool5"})
+    ref_f, xw = {}, cur.clone()
+    with torch.no_grad():
+        for name, layer in model._modules.items():
+            xw = layer(xw)
+            if name in ("4", "36"):
+                ref_f["pool1" if name == "4" else "pool5"] = xw.clone()
+            if name == "29":                       # the in-place ReLU after conv5_1: what the reference's tap aliases
+                ref_f["conv5_1"] = xw.clone()
+    for k in feats:
+        assert feats[k].shape == ref_f[k].shape
+        assert float((feats[k].cpu() - ref_f[k]).abs().max()) <= 2e-4 * float(ref_f[k].abs().max())

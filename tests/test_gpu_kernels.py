@@ -156,14 +156,15 @@ def test_conv3x3_dgrad_unpool(dev, ops, N, Cin, Cout, H, W):
     _scale_close(gx, x.grad, 5e-5, "dgrad_unpool")
 
 
-def test_maxpool_matches_torch(dev, ops):
+@pytest.mark.parametrize("H,W", [(12, 20), (11, 21), (7, 6), (2, 3)])
+def test_maxpool_matches_torch(dev, ops, H, W):
+    """incl. odd sizes: MaxPool2d floors (last row / column dropped)"""
     torch.manual_seed(0)
-    y = torch.randn(2, 5, 12, 20)
+    y = torch.randn(2, 5, H, W)
     y[0, 0, 0:2, 0:2] = 0.0                                   # tie: the first element wins
     ref, ridx = F.max_pool2d(y, 2, 2, return_indices=True)
     p, idx = ops.maxpool2x2(y.to(dev))
     torch.testing.assert_close(p.cpu(), ref, rtol=0, atol=0)
-    W = 20
     rr_, cc_ = ridx // W, ridx % W
     local = (rr_ % 2) * 2 + (cc_ % 2)
     np.testing.assert_array_equal(idx.cpu().numpy(), local.numpy().astype(np.uint8))
