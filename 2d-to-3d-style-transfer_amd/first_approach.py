@@ -65,8 +65,7 @@ def main(argv=None):
             targets = finalize_tensor(style_transfer(start, content, style, run.vgg, steps=args.n_style_transfer_steps,
                                                      style_weight=args.style_weight, content_weight=args.content_weight,
                                                      lr=args.style_transfer_lr))
-            for j, view in enumerate(targets):
-                tensor_to_image(view).save(f"{run.image_dir}/view_{vb.lo + j}.png")
+            run.save_views(targets, vb.lo)
 
         # phase B: masked MSE between the renders and the stylised views
         shown = 0

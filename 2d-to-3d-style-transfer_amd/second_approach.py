@@ -76,8 +76,7 @@ def main(argv=None):
                 loss = loss + extra
 
             if args.save_every and steps_done % args.save_every == 0:
-                for j, view in enumerate(current):
-                    tensor_to_image(view).save(f"{run.image_dir}/view_{vb.lo + j}.png")
+                run.save_views(current, vb.lo)          # encoded by worker threads, off the step's critical path
 
             loss.backward()
             run.optimizer.step()                    # gradient all-reduce over ranks + fused Adam

@@ -57,8 +57,7 @@ def main(argv=None):
                                                          steps=args.n_style_transfer_steps, style_weight=args.style_weight,
                                                          content_weight=args.content_weight, lr=args.style_transfer_lr))
                 if rnd == args.n_rounds - 1:
-                    for j, view in enumerate(targets):
-                        tensor_to_image(view).save(f"{run.image_dir}/view_{vb.lo + j}.png")
+                    run.save_views(targets, vb.lo)
             loss = torch.zeros((), device=run.device)
             for _ in range(args.n_mse_steps):
                 run.optimizer.zero_grad()

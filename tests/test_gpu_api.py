@@ -621,3 +621,25 @@ def test_sizes_off_the_fast_path_match_oracle(mods, vgg, S, B):
     for k in feats:
         assert feats[k].shape == ref_f[k].shape
         assert float((feats[k].cpu() - ref_f[k]).abs().max()) <= 2e-4 * float(ref_f[k].abs().max())
+
+
+def test_async_png_writer_writes_the_pixels_tensor_to_image_would(mods, tmp_path):
+    """The per-step dumps go through worker threads (st3d.cli.AsyncImageWriter); the files must hold exactly what the
+    reference's tensor_to_image(...).save(...) writes (clamp, x255, truncate)."""
+    _, _, U, dev = mods
+    from PIL import Image
+    from st3d.cli import AsyncImageWriter
+    g = torch.Generator().manual_seed(0)
+    imgs = (torch.rand(5, 3, 33, 47, generator=g) * 1.4 - 0.2).to(dev)         # values outside [0,1] too
+    w = AsyncImageWriter(workers=3, depth=1)
+    for rep in range(3):                                                       # more batches than `depth`: back-pressure path
+        w.submit(imgs + 0.01 * rep, [str(tmp_path / f"r{rep}_v{k}.png") for k in range(5)])
+    w.flush()
+    for rep in range(3):
+        for k in range(5):
+            got = np.asarray(Image.open(tmp_path / f"r{rep}_v{k}.png"))
+            want = np.asarray(U.tensor_to_image(imgs[k] + 0.01 * rep))
+            np.testing.assert_array_equal(got, want)
+    with pytest.raises(Exception):                                             # a failed write surfaces at flush
+        w.submit(imgs[:1], [str(tmp_path / "no_such_dir" / "x.png")])
+        w.flush()
