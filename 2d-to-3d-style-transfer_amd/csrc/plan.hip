@@ -330,6 +330,27 @@ extern "C" int st3d_plan_set_content(st3d_plan *p, const float *content, int n, 
     return ST3D_OK;
 }
 
+// content features (conv4_2 of the content images) out of / into the plan: lets a caller that alternates between several
+// view batches keep each batch's target and skip recomputing it (a device copy instead of a VGG forward to conv4_2)
+extern "C" int st3d_plan_get_content_features(st3d_plan *p, float *out, int n, st3d_stream_t stream) {
+    ST3D_CHECK_ARG(p && out && n > 0 && n <= p->B);
+    if (!p->have_content) {
+        st3d::set_error("st3d_plan_get_content_features: no content target set");
+        return ST3D_E_STATE;
+    }
+    const size_t cnt = (size_t)n * p->C[kContentTap] * p->H[kContentTap] * p->W[kContentTap];
+    ST3D_HIP(hipMemcpyAsync(out, p->content_target, cnt * sizeof(float), hipMemcpyDeviceToDevice, st3d::as_stream(stream)));
+    return ST3D_OK;
+}
+
+extern "C" int st3d_plan_set_content_features(st3d_plan *p, const float *feat, int n, st3d_stream_t stream) {
+    ST3D_CHECK_ARG(p && feat && n > 0 && n <= p->B);
+    const size_t cnt = (size_t)n * p->C[kContentTap] * p->H[kContentTap] * p->W[kContentTap];
+    ST3D_HIP(hipMemcpyAsync(p->content_target, feat, cnt * sizeof(float), hipMemcpyDeviceToDevice, st3d::as_stream(stream)));
+    p->have_content = true;
+    return ST3D_OK;
+}
+
 extern "C" int st3d_plan_set_style(st3d_plan *p, const float *style, int style_batch, int n, st3d_stream_t stream) {
     ST3D_CHECK_ARG(p && style && n > 0 && n <= p->B && (style_batch == 1 || style_batch == n));
     hipStream_t s = st3d::as_stream(stream);

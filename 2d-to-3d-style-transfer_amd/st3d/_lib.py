@@ -78,6 +78,8 @@ SIGNATURES = {
     "st3d_plan_activation": (c_int, [ctypes.c_void_p, c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(c_int),
                                      ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "st3d_plan_set_content": (c_int, [ctypes.c_void_p, c_f32p, c_int, c_stream]),
+    "st3d_plan_get_content_features": (c_int, [ctypes.c_void_p, c_f32p, c_int, c_stream]),
+    "st3d_plan_set_content_features": (c_int, [ctypes.c_void_p, c_f32p, c_int, c_stream]),
     "st3d_plan_set_style": (c_int, [ctypes.c_void_p, c_f32p, c_int, c_int, c_stream]),
     "st3d_plan_loss": (c_int, [ctypes.c_void_p, c_f32p, c_int, c_int, c_float, c_float, c_f32p, c_f32p, c_stream]),
     "st3d_plan_profile": (c_int, [ctypes.c_void_p, c_int]),

@@ -170,12 +170,31 @@ class PerceptualPlan:
     def _key(t):
         return (t.data_ptr(), t._version, tuple(t.shape))
 
+    CONTENT_CACHE = 8      # targets kept (67 MB each for 8 views at 512^2); the reference alternates ceil(n_views / batch) batches
+
     def set_content(self, content, force=False):
+        """conv4_2 of `content` becomes the plan's content target.  Keyed on the tensor's identity/version: a caller that
+        cycles through a few fixed content batches (second_approach.py:145-160) pays the VGG forward once per batch, a
+        device copy afterwards; new or modified tensors (``--content_background noise``) are recomputed."""
         k = self._key(content)
-        if force or k != self._content_key:
+        if not force and k == self._content_key:
+            return
+        n = content.shape[0]
+        cache = self.__dict__.setdefault("_content_cache", {})
+        hit = None if force else cache.get(k)
+        if hit is not None:         # (features, the tensor: holding it keeps its address from being reused while cached)
+            call("st3d_plan_set_content_features", self._h, dptr(hit[0]), n, stream_ptr())
+        else:
             c = content.detach().to(torch.float32).contiguous()
-            call("st3d_plan_set_content", self._h, dptr(c), c.shape[0], stream_ptr())
-            self._content_key = k
+            call("st3d_plan_set_content", self._h, dptr(c), n, stream_ptr())
+            if self._content_key is not None and self.CONTENT_CACHE > 0:
+                # a second distinct batch showed up: start keeping targets (single-batch runs never pay the copy)
+                feats = torch.empty((n, 512, self.S // 8, self.S // 8), dtype=torch.float32, device=self.vgg.device)
+                call("st3d_plan_get_content_features", self._h, dptr(feats), n, stream_ptr())
+                if len(cache) >= self.CONTENT_CACHE:
+                    cache.pop(next(iter(cache)))
+                cache[k] = (feats, content)
+        self._content_key = k
 
     def set_style(self, style, n, force=False):
         k = self._key(style) + (n,)

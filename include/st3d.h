@@ -244,6 +244,11 @@ int st3d_plan_activation(st3d_plan *plan, int module_idx, float **ptr, int *C, i
 /* targets (losses.py:18-25): conv4_2 features of content (B,3,S,S); Grams of style
  * (style_batch == 1: one image broadcast over the batch, as second_approach.py:157 repeats it) */
 int st3d_plan_set_content(st3d_plan *plan, const float *content, int n, st3d_stream_t stream);
+/* the content target (conv4_2 features, n x 512 x S/8 x S/8 floats) out of / into the plan: a caller alternating between
+ * several view batches (second_approach.py:145-160 with n_views > batch_size) can keep each batch's target instead of
+ * recomputing it every step */
+int st3d_plan_get_content_features(st3d_plan *plan, float *out, int n, st3d_stream_t stream);
+int st3d_plan_set_content_features(st3d_plan *plan, const float *features, int n, st3d_stream_t stream);
 int st3d_plan_set_style(st3d_plan *plan, const float *style, int style_batch, int n, st3d_stream_t stream);
 /* loss (losses.py:28-42) of current (n,3,S,S) and, if grad_current != NULL, d loss/d current.
  * batch_denom = the batch size the means divide by (n, or the GLOBAL batch when views are

@@ -643,3 +643,36 @@ def test_async_png_writer_writes_the_pixels_tensor_to_image_would(mods, tmp_path
     with pytest.raises(Exception):                                             # a failed write surfaces at flush
         w.submit(imgs[:1], [str(tmp_path / "no_such_dir" / "x.png")])
         w.flush()
+
+
+def test_content_targets_of_alternating_batches_are_kept(mods, vgg, monkeypatch):
+    """second_approach.py with n_views > batch_size alternates between a few fixed content batches: the plan keeps each
+    batch's conv4_2 target (device copy) instead of recomputing it; modified tensors are recomputed; results are the
+    ones a forced recomputation gives, bit for bit."""
+    _, L, _, dev = mods
+    import st3d.vgg as V
+    S, B = 64, 2
+    g = torch.Generator().manual_seed(0)
+    cur = torch.rand(B, 3, S, S, generator=g).to(dev)
+    sty = torch.rand(1, 3, S, S, generator=g).to(dev).expand(B, -1, -1, -1)
+    batches = [torch.rand(B, 3, S, S, generator=g).to(dev) for _ in range(3)]
+    calls = []
+    real = V.call
+    monkeypatch.setattr(V, "call", lambda name, *a: (calls.append(name), real(name, *a))[1])
+    plan = vgg.plan(B, S)
+    plan.set_content(batches[0], force=True)                      # known starting point whatever ran before
+    plan.__dict__["_content_cache"] = {}
+    ref = []
+    for c in batches:
+        plan.set_content(c, force=True)
+        ref.append(L.compute_perceptual_loss(cur, c, sty, vgg).item())
+    calls.clear()
+    seen = [L.compute_perceptual_loss(cur, batches[i % 3], sty, vgg).item() for i in range(9)]
+    assert seen == [ref[i % 3] for i in range(9)]
+    n_forward = calls.count("st3d_plan_set_content")
+    assert n_forward <= 4, calls                                   # at most one forward per batch (+1 before caching starts)
+    assert calls.count("st3d_plan_set_content_features") >= 4
+    batches[1].mul_(0.5)                                            # in-place change -> new version -> recomputed
+    calls.clear()
+    changed = L.compute_perceptual_loss(cur, batches[1], sty, vgg).item()
+    assert "st3d_plan_set_content" in calls and changed != ref[1]
