@@ -10,6 +10,8 @@
 //   backward = "NN": A = D (M=C, K=C), B = F as [K][N=HW].
 // Arithmetic intensity is 32 flop/B per 128x128 tile (A/B tiles re-read through L2), at the
 // fp32 ridge for C = 64 where F (the largest activation) is streamed exactly once.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -199,12 +201,19 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const float *__restric
     }
 }
 
-// K split: enough workgroups to fill the chip twice over (256 CUs x 2 resident workgroups x 2), but
+// K split: enough workgroups to fill the chip a few times over (256 CUs x 2 resident workgroups x 1..4), but
 // at least 8 K-chunks of work per workgroup and at most 256 slabs.
 int gram_split(int B, int C, int HW, int *kper) {
     const int nt = (C % 128 == 0) ? C / 128 : (C + 63) / 64;
     const int pairs = nt * (nt + 1) / 2;
-    int ns = (1024 + pairs * B - 1) / (pairs * B);
+    // workgroups aimed for, measured per style layer of config 2 (tools/gram_sweep.py): the deep layers (few tiles,
+    // short K) want more, thinner splits; C = 128 fewer
+    const int target = C >= 256 ? 2048 : (C == 128 ? 512 : 1024);
+    int ns = (target + pairs * B - 1) / (pairs * B);
+    if (const char *ev = getenv("ST3D_GRAM_TARGET_WGS")) {       // tuning knob (tools/gram_sweep.py): workgroups aimed for
+        const int t = atoi(ev);
+        if (t > 0) ns = (t + pairs * B - 1) / (pairs * B);
+    }
     const int ns_bytes = (HW + 2047) / 2048;            // never more than 2048 pixels per workgroup
     if (ns < ns_bytes) ns = ns_bytes;
     const int ns_max = (HW + 8 * KCH - 1) / (8 * KCH);
@@ -263,7 +272,13 @@ extern "C" int st3d_gram_bwd(const float *D, const float *feat, int B, int C, in
     g.nsplit = 1; g.kper = (C + KCH - 1) / KCH * KCH; g.sSplit = 0;
     g.tri = 0; g.coef = coef; g.accumulate = accumulate;
     hipStream_t s = st3d::as_stream(stream);
-    if (C % 128 == 0) {
+    // 128-row tiles only where they leave enough workgroups (>= 1024) and D is wide (measured, tools/gram_bwd_sweep.py:
+    // C = 128 at 256^2 runs 18 % faster on 64-row tiles, conv5_1's 32^2 14 %; C >= 256 at >= 64^2 is indifferent)
+    const char *force = getenv("ST3D_GRAM_BWD_MT");             // tuning knob: "1" / "2" force 64- / 128-row tiles
+    bool tall = C % 128 == 0 && C >= 256 && (long)(C / 128) * st3d::cdiv(HW, 128) * B >= 1024;
+    if (force && force[0] == '1') tall = false;
+    if (force && force[0] == '2' && C % 128 == 0) tall = true;
+    if (tall) {
         g.tiles_m = C / 128; g.tiles_n = st3d::cdiv(HW, 128);
         gemm_kernel<2, 2, 1><<<dim3(g.tiles_m * g.tiles_n, 1, B), 256, 0, s>>>(g);
     } else {
