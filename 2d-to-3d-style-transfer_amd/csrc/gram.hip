@@ -42,7 +42,9 @@ __device__ __forceinline__ float4 load4(const float *p, int remain, bool aligned
 }
 
 // MT/NT: 32x32 MFMA tiles per wave along M/N.  BMODE 0: B is [N][K]; 1: B is [K][N].
-template <int MT, int NT, int BMODE>
+// DIAG 1: the only tile of a Gram forward whose C fits one tile (C = 64, 128) -- the B tile IS the A tile, fetched and
+// staged once (compile-time: the run-time test cost the multi-tile layers more than it saved them).
+template <int MT, int NT, int BMODE, int DIAG = 0>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     constexpr int TM = 2 * MT * 32, TN = 2 * NT * 32;
     constexpr int LA = TM + 1;
@@ -66,6 +68,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     }
     const int split = blockIdx.y, b = blockIdx.z;
     const int m0 = ti * TM, n0 = tj * TN;
+    static_assert(!DIAG || (BMODE == 0 && MT == NT), "DIAG is the single-tile Gram forward");
+    constexpr bool diag = DIAG != 0;
     const int kbeg = split * g.kper, kend = min(g.K, kbeg + g.kper);
 
     const float *Ab = g.A + b * g.sA;
@@ -90,6 +94,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
             av[i] = (gm < g.M) ? load4(Ab + (size_t)gm * g.lda + gk, kend - gk, a_al && ((gk & 3) == 0))
                                : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        if (diag) return;
 #pragma unroll
         for (int i = 0; i < B4; ++i) {
             const int e = tid + i * 256;
@@ -113,6 +118,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
             As[(kq + 0) * LA + row] = av[i].x; As[(kq + 1) * LA + row] = av[i].y;
             As[(kq + 2) * LA + row] = av[i].z; As[(kq + 3) * LA + row] = av[i].w;
         }
+        if (diag) return;
 #pragma unroll
         for (int i = 0; i < B4; ++i) {
             const int e = tid + i * 256;
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         __syncthreads();
         if (k0 + KCH < kend) load_tiles(k0 + KCH);   // in flight during the MFMAs below
         const float *pa = As + lhi * LA + wm * (MT * 32) + l31;
-        const float *pb = Bs + lhi * LB + wn * (NT * 32) + l31;
+        const float *pb = (diag ? As : Bs) + lhi * LB + wn * (NT * 32) + l31;      // (LA == LB when TM == TN)
 #pragma unroll
         for (int kk = 0; kk < KCH / 2; ++kk) {
             float a[MT], bb[NT];
@@ -216,7 +222,7 @@ int gram_split(int B, int C, int HW, int *kper) {
     }
     const int ns_bytes = (HW + 2047) / 2048;            // never more than 2048 pixels per workgroup
     if (ns < ns_bytes) ns = ns_bytes;
-    const int ns_max = (HW + 8 * KCH - 1) / (8 * KCH);
+    const int ns_max = (HW + 8 * KCH - 1) / (8 * KCH);   // at least 8 K-chunks (256 pixels) of work per workgroup (4 measured slower)
     if (ns > ns_max) ns = ns_max;
     if (ns > 256) ns = 256;
     if (ns < 1) ns = 1;
@@ -252,7 +258,10 @@ extern "C" int st3d_gram_fwd(const float *feat, int B, int C, int HW, void *work
     const int TM = (C % 128 == 0) ? 128 : 64;
     g.tiles_m = g.tiles_n = st3d::cdiv(C, TM);
     dim3 grid(g.tiles_n * (g.tiles_n + 1) / 2, g.nsplit, B);
-    if (TM == 128) gemm_kernel<2, 2, 0><<<grid, 256, 0, s>>>(g);
+    if (g.tiles_n == 1) {           // one (diagonal) tile: A and B tiles coincide
+        if (TM == 128) gemm_kernel<2, 2, 0, 1><<<grid, 256, 0, s>>>(g);
+        else gemm_kernel<1, 1, 0, 1><<<grid, 256, 0, s>>>(g);
+    } else if (TM == 128) gemm_kernel<2, 2, 0><<<grid, 256, 0, s>>>(g);
     else gemm_kernel<1, 1, 0><<<grid, 256, 0, s>>>(g);
     ST3D_LAUNCH_CHECK();
     gram_reduce_kernel<<<dim3(st3d::cdiv((long)C * C, 64), B), 256, 0, s>>>(g.C, g.nsplit, C, TM, g.sSplit, g.sC, gram);
