@@ -81,6 +81,8 @@ __global__ __launch_bounds__(NT, 2) void wino_kernel(const WinoArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
     float *sP = smem;                          // [3][KS][PR][PCP]
 
+    unsigned long long t_entry = 0, t_loop0 = 0, t_loop1 = 0;      // DBG builds: whole-workgroup phase stamps
+    if (DBG) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_entry) :: "memory"); }
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lhi = lane >> 5;
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(NT, 2) void wino_kernel(const WinoArgs a) {
     // must sit between them in program order).  Tail stages redo clamped, harmless work.
     int pb = 0;            // patch buffer of stage c (mod 3)
     unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
-    if (DBG) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast) :: "memory"); }
+    if (DBG) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast) :: "memory"); t_loop0 = tlast; }
 #define STAMP(k) if (DBG) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); tsum[k] += t_ - tlast; tlast = t_; }
     // Per stage each wave alternates four 8-MFMA bursts (M) with four overhead slots (O); a wave
     // issues in order, so while it sits in a burst nothing else of it issues, and while it is in
@@ -336,6 +338,7 @@ __global__ __launch_bounds__(NT, 2) void wino_kernel(const WinoArgs a) {
     }
 #undef WINO_MFMA
 #undef WINO_ULOAD
+    if (DBG) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_loop1) :: "memory"); }
     if (DBG && a.dbg && blockIdx.x == 300 && lane == 0) { for (int k = 0; k < 8; ++k) a.dbg[wave * 8 + k] = tsum[k]; }
 
     // ---- epilogue: Y = A^T M A.  Along b in registers (z_j), along a through LDS.
@@ -393,6 +396,12 @@ __global__ __launch_bounds__(NT, 2) void wino_kernel(const WinoArgs a) {
             a.yp[po] = best;
             if (a.yidx) a.yidx[po] = (uint8_t)bi;
         }
+    }
+    if (DBG && a.dbg && blockIdx.x == 300 && lane == 0) {       // prologue / loop / epilogue cycles of this wave
+        unsigned long long t_end;
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_end) :: "memory");
+        a.dbg[64 + wave * 4 + 0] = t_loop0 - t_entry; a.dbg[64 + wave * 4 + 1] = t_loop1 - t_loop0;
+        a.dbg[64 + wave * 4 + 2] = t_end - t_loop1; a.dbg[64 + wave * 4 + 3] = t_end - t_entry;
     }
 }
 
