@@ -242,10 +242,15 @@ __global__ __launch_bounds__(NT, 2) void wino_kernel(const WinoArgs a) {
     // LDS stores at the bottom) around their MFMAs, waves 4-7 ("B") store at the top what they
     // loaded during the previous stage.  Both do the same work between two barriers.
     const bool isA = __builtin_amdgcn_readfirstlane(wave) < 4;
+    unsigned long long tp[6] = {0, 0, 0, 0, 0, 0};
+#define PSTAMP(k) if (DBG) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tp[k]) :: "memory"); }
+    PSTAMP(0)
     gload(0);
     lstore(0);
+    PSTAMP(1)
     gload(nstages > 1 ? 1 : 0);
     lstore(1);
+    PSTAMP(2)
     if (!isA) gload(min(2, nstages - 1));      // B holds stage c+2 in registers across the barrier
     auto uload = [&](int sub, f32x4 &u0, f32x4 &u1) __attribute__((always_inline)) {
         const unsigned so = (unsigned)min(sub, nsub - 1) * 16384u;
@@ -254,11 +259,14 @@ __global__ __launch_bounds__(NT, 2) void wino_kernel(const WinoArgs a) {
     };
     f32x4 ua0, ua1;
     uload(0, ua0, ua1);
+    PSTAMP(3)
     __syncthreads();
+    PSTAMP(4)
     Raw draw;
     Bop bcur, bnext;
     pread(0, 0, draw);
     bcompute(draw, bcur);
+    PSTAMP(5)
 
 #define WINO_MFMA(ua, bv, ks, q)                                                                      \
         acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[q], bv.v[ks][0][q], acc[q][0], 0, 0, 0);   \
@@ -402,6 +410,11 @@ __global__ __launch_bounds__(NT, 2) void wino_kernel(const WinoArgs a) {
         asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_end) :: "memory");
         a.dbg[64 + wave * 4 + 0] = t_loop0 - t_entry; a.dbg[64 + wave * 4 + 1] = t_loop1 - t_loop0;
         a.dbg[64 + wave * 4 + 2] = t_end - t_loop1; a.dbg[64 + wave * 4 + 3] = t_end - t_entry;
+        if (wave == 0 || wave == 4) {       // prologue split: setup | gload0+lstore0 | gload1+lstore1 | uload | barrier | pread+bcompute
+            unsigned long long *o = a.dbg + 96 + (wave >> 2) * 8;
+            o[0] = tp[0] - t_entry; o[1] = tp[1] - tp[0]; o[2] = tp[2] - tp[1]; o[3] = tp[3] - tp[2]; o[4] = tp[4] - tp[3];
+            o[5] = tp[5] - tp[4];
+        }
     }
 }
 

@@ -27,10 +27,11 @@ if not os.environ.get("ST3D_WINO_DBG"):
     t = timeit(lambda: ops.conv3x3_fwd(x, wf, b, Cout))
     print(f"direct {t*1e3:8.1f} us  {gf/t:7.1f} TF/s")
 if os.environ.get("WINO_STAMP"):
-    dbg = torch.zeros(96, dtype=torch.int64, device=dev)
+    dbg = torch.zeros(112, dtype=torch.int64, device=dev)
     os.environ["ST3D_WINO_STAMP"] = str(dbg.data_ptr())
     ops.wino_fwd(x, uf, b, Cout); torch.cuda.synchronize()
-    whole = dbg.cpu().numpy()[64:].reshape(8, 4)
+    whole = dbg.cpu().numpy()[64:96].reshape(8, 4)
+    pro = dbg.cpu().numpy()[96:112].reshape(2, 8)
     d = dbg.cpu().numpy()[:64].reshape(8, 8)
     nst = Cin // 8
     names = ["(loop)", "M1", "O:gload,uload,pread", "M2", "O:bcomp + M3", "O:uload,pread + M4", "O:bcomp,lstore", "barrier"]
@@ -38,3 +39,5 @@ if os.environ.get("WINO_STAMP"):
         print("wave", w, " ".join(f"{names[k]}={d[w,k]/nst:7.0f}" for k in range(8)), " total/stage=%.0f" % (d[w].sum()/nst))
     for w in range(8):
         print("wave", w, "prologue=%d loop=%d epilogue=%d total=%d cycles" % tuple(whole[w]))
+    for i, w in enumerate((0, 4)):
+        print("wave", w, "prologue split: setup=%d gload0+lstore0=%d gload1+lstore1=%d uload=%d barrier=%d pread+bcompute=%d" % tuple(pro[i][:6]))
