@@ -16,6 +16,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+def pytest_sessionstart(session):
+    """libst3d.so travels with the tree (git-ignored, built by __graft_entry__.build()); on a checkout without it,
+    compile it once up front (hipcc cross-compiles without a GPU) instead of failing every test that loads it.
+    Nothing falls back to a CPU path if this does not produce the library."""
+    so = os.path.join(PKG, "lib", "libst3d.so")
+    if not os.path.exists(so) and os.path.exists("/opt/rocm/bin/hipcc"):
+        import __graft_entry__ as g
+        g.build()
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
