@@ -125,6 +125,10 @@ def main():
                     help="optimization_target (BASELINE configs[1] = texture; configs[4] = both)")
     args = ap.parse_args()
 
+    if not os.path.exists(os.path.join(PKG, "lib", "libst3d.so")) and int(os.environ.get("RANK", "0")) == 0 \
+            and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        import __graft_entry__ as _ge           # a checkout without the prebuilt library: compile it (there is no CPU fallback)
+        _ge.build()
     from st3d import optim as st3d_optim
     rank, world, local = st3d_optim.init_distributed()
     if world != args.gpus:
