@@ -52,6 +52,8 @@ def build(force=False, jobs=4, verbose=True):
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJDIR, src.replace(".hip", ".o"))
         objs.append(o)
+        if os.environ.get("ST3D_WINO_DEBUG") and src == "wino.hip":
+            flags = flags + ["-DST3D_WINO_DEBUG"]      # s_memtime stamps for tools/wino_bench.py; never in the shipped library
         if force or _newer(s, o, hdrs):
             todo.append([HIPCC] + COMMON + flags + ["-c", s, "-o", o])
 

@@ -119,10 +119,14 @@ class _MaskedMseFn(torch.autograd.Function):
         return (ctx.grad * grad_out if ctx.grad is not None else None), None, None
 
 
-def _masked_mse(rendered, masks, target_rendered):
+def _masked_mse(rendered, masks, target_rendered, batch_denom=None):
     if not rendered.is_cuda:
         raise RuntimeError("st3d runs on the GPU (libst3d); got CPU tensors -- there is no CPU fallback")
-    return _MaskedMseFn.apply(rendered, masks, target_rendered)
+    loss = _MaskedMseFn.apply(rendered, masks, target_rendered)
+    if batch_denom is not None and batch_denom != rendered.shape[0]:
+        # views sharded over ranks: the mean over this rank's views becomes its share of the mean over the whole batch
+        loss = loss * (rendered.shape[0] / float(batch_denom))
+    return loss
 
 
 def _mesh_terms(verts, target_verts, mesh, weights):
@@ -131,13 +135,16 @@ def _mesh_terms(verts, target_verts, mesh, weights):
     return _mesh_losses.mesh_terms(verts, target_verts, mesh, weights)      # one fused forward+gradient call
 
 
-def compute_first_approach_loss(rendered, masks, target_rendered, verts, target_verts, mesh, weights, opt_type):
+def compute_first_approach_loss(rendered, masks, target_rendered, verts, target_verts, mesh, weights, opt_type, *,
+                                batch_denom=None):
     # 'texture' ignores main_loss_weight (reference :75); an unknown opt_type leaves `loss` unbound and
-    # raises UnboundLocalError at the return, as the reference does (:98)
+    # raises UnboundLocalError at the return, as the reference does (:98).
+    # batch_denom (views sharded over ranks): only the IMAGE term is a mean over views and is scaled to this rank's
+    # share of the global batch; the mesh terms are view-independent and already enter with 1/world per rank.
     if opt_type == 'texture':
-        loss = _masked_mse(rendered, masks, target_rendered)
+        loss = _masked_mse(rendered, masks, target_rendered, batch_denom)
     elif opt_type in ('mesh', 'both'):
-        loss = weights['main_loss_weight'] * _masked_mse(rendered, masks, target_rendered)
+        loss = weights['main_loss_weight'] * _masked_mse(rendered, masks, target_rendered, batch_denom)
         loss = loss + _mesh_terms(verts, target_verts, mesh, weights)
     return loss
 

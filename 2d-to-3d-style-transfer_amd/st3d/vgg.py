@@ -142,6 +142,7 @@ class PerceptualPlan:
         call("st3d_plan_create", ctypes.byref(h), vgg._h, B, S)
         self._h = h
         self._content_key = self._style_key = None
+        self._content_ref = self._style_ref = None      # the keyed tensors themselves (see _same)
         self.loss_buf = torch.zeros((3,), dtype=torch.float32, device=vgg.device)
 
     def close(self):
@@ -170,6 +171,14 @@ class PerceptualPlan:
     def _key(t):
         return (t.data_ptr(), t._version, tuple(t.shape))
 
+    @staticmethod
+    def _same(key, ref, k, t):
+        """Is `t` the tensor a target was computed from, unmodified?  (address, version, shape) alone is unsound:
+        libst3d kernels write into fresh ``torch.empty`` buffers (version stays 0) and the allocator hands a freed
+        address to the next batch of the same shape, so the keyed tensor is held (`ref`) -- its address cannot be
+        reused while it is the current target -- and compared by identity of storage + version."""
+        return key is not None and ref is not None and k == key and ref.data_ptr() == t.data_ptr()
+
     CONTENT_CACHE = 8      # targets kept (67 MB each for 8 views at 512^2); the reference alternates ceil(n_views / batch) batches
 
     def set_content(self, content, force=False):
@@ -177,7 +186,7 @@ class PerceptualPlan:
         cycles through a few fixed content batches (second_approach.py:145-160) pays the VGG forward once per batch, a
         device copy afterwards; new or modified tensors (``--content_background noise``) are recomputed."""
         k = self._key(content)
-        if not force and k == self._content_key:
+        if not force and self._same(self._content_key, self._content_ref, k, content):
             return
         n = content.shape[0]
         cache = self.__dict__.setdefault("_content_cache", {})
@@ -194,11 +203,11 @@ class PerceptualPlan:
                 if len(cache) >= self.CONTENT_CACHE:
                     cache.pop(next(iter(cache)))
                 cache[k] = (feats, content)
-        self._content_key = k
+        self._content_key, self._content_ref = k, content
 
     def set_style(self, style, n, force=False):
         k = self._key(style) + (n,)
-        if force or k != self._style_key:
+        if force or not self._same(self._style_key, self._style_ref, k, style):
             s = style.detach().to(torch.float32).contiguous()
             sb = s.shape[0]
             if sb > 1 and s.stride(0) == 0:
@@ -207,7 +216,7 @@ class PerceptualPlan:
                 sb = 1
             s = s[:1].contiguous() if sb == 1 else s
             call("st3d_plan_set_style", self._h, dptr(s), sb, n, stream_ptr())
-            self._style_key = k
+            self._style_key, self._style_ref = k, style
 
     def loss(self, current, style_weight, content_weight, batch_denom=None, want_grad=True):
         """-> (loss_buf view [total, content, style], grad (n,3,S,S) or None)."""

@@ -66,9 +66,8 @@ def main(argv=None):
                     rendered, cov = render_meshes(run.renderer, mesh, cams)
                     loss = compute_first_approach_loss(rendered=rendered, masks=cov, target_rendered=targets,
                                                        verts=run.opt['verts'], target_verts=run.original_verts, mesh=mesh,
-                                                       weights=run.loss_weights, opt_type=args.optimization_target)
-                    if run.world > 1:
-                        loss = loss * (n_local / vb.size)
+                                                       weights=run.loss_weights, opt_type=args.optimization_target,
+                                                       batch_denom=vb.size)
                     loss.backward()
                 else:
                     run.zero_contribution()

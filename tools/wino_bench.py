@@ -26,7 +26,7 @@ print(f"wino   {t*1e3:8.1f} us  {gf/t:7.1f} TF/s(direct-equivalent)  mfma util {
 if not os.environ.get("ST3D_WINO_DBG"):
     t = timeit(lambda: ops.conv3x3_fwd(x, wf, b, Cout))
     print(f"direct {t*1e3:8.1f} us  {gf/t:7.1f} TF/s")
-if os.environ.get("WINO_STAMP"):
+if os.environ.get("WINO_STAMP"):      # needs a library built with ST3D_WINO_DEBUG=1 (build.py)
     dbg = torch.zeros(112, dtype=torch.int64, device=dev)
     os.environ["ST3D_WINO_STAMP"] = str(dbg.data_ptr())
     ops.wino_fwd(x, uf, b, Cout); torch.cuda.synchronize()
