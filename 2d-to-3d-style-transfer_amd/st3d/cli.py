@@ -145,7 +145,8 @@ class Run:
         self.rank, self.world, local = st3d_optim.init_distributed()
         if not torch.cuda.is_available():
             raise RuntimeError("st3d needs an MI355X (libst3d has no CPU fallback)")
-        self.device = torch.device(f"cuda:{local}")
+        # one GPU per rank; only a gloo rehearsal (ST3D_DIST_BACKEND=gloo) may put several ranks on one card
+        self.device = torch.device(f"cuda:{local % max(torch.cuda.device_count(), 1)}")
         torch.cuda.set_device(self.device)
         _u.device = _s.device = _l.device = self.device
         if args.seed is not None:

@@ -82,9 +82,9 @@ static inline float pix_to_ndc(int i, int S)
  * Outputs (S,S): pix_to_face int32 (-1 = background), zbuf, bary (S,S,3), dists (signed
  * squared distance to the nearest edge; negative inside); -1 fill elsewhere.
  */
-void ref_rasterize(const float *verts_ndc, const int32_t *faces, int F, int S,
-                   float blur_radius, int nthreads,
-                   int32_t *pix_to_face, float *zbuf, float *bary, float *dists)
+static void rasterize_impl(const float *verts_ndc, const int32_t *faces, int F, int S,
+                           float blur_radius, int nthreads, int row_lists,
+                           int32_t *pix_to_face, float *zbuf, float *bary, float *dists)
 {
     const float pad = sqrtf(blur_radius);
     (void)nthreads;
@@ -93,11 +93,28 @@ void ref_rasterize(const float *verts_ndc, const int32_t *faces, int F, int S,
 #endif
     for (int yi = 0; yi < S; ++yi) {
         const float yf = pix_to_ndc(S - 1 - yi, S);
+        /* row_lists: the faces whose padded y-extent contains this row's centre, in face order -- the SAME y test
+         * the per-pixel loop below repeats, evaluated once per row, so the result is identical to the plain
+         * all-faces loop (checked bit for bit in tests/test_oracle_raster.py); it only skips work. */
+        int32_t *row = NULL;
+        int nrow = F;
+        if (row_lists) {
+            row = (int32_t *)malloc((size_t)(F > 0 ? F : 1) * sizeof(int32_t));
+            nrow = 0;
+            for (int f = 0; f < F; ++f) {
+                const float y0 = verts_ndc[3 * faces[3 * f] + 1], y1 = verts_ndc[3 * faces[3 * f + 1] + 1];
+                const float y2 = verts_ndc[3 * faces[3 * f + 2] + 1];
+                const float ymin = fminf(y0, fminf(y1, y2)) - pad, ymax = fmaxf(y0, fmaxf(y1, y2)) + pad;
+                if (yf > ymax || yf < ymin) continue;
+                row[nrow++] = f;
+            }
+        }
         for (int xi = 0; xi < S; ++xi) {
             const float xf = pix_to_ndc(S - 1 - xi, S);
             int best_f = -1;
             float best_z = 0.f, best_d = 0.f, bw0 = 0.f, bw1 = 0.f, bw2 = 0.f;
-            for (int f = 0; f < F; ++f) {
+            for (int k = 0; k < nrow; ++k) {
+                const int f = row ? row[k] : k;
                 const int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
                 const float x0 = verts_ndc[3 * i0], y0 = verts_ndc[3 * i0 + 1], z0 = verts_ndc[3 * i0 + 2];
                 const float x1 = verts_ndc[3 * i1], y1 = verts_ndc[3 * i1 + 1], z1 = verts_ndc[3 * i1 + 2];
@@ -145,7 +162,23 @@ void ref_rasterize(const float *verts_ndc, const int32_t *faces, int F, int S,
                 bary[3 * p] = -1.f; bary[3 * p + 1] = -1.f; bary[3 * p + 2] = -1.f;
             }
         }
+        free(row);
     }
+}
+
+void ref_rasterize(const float *verts_ndc, const int32_t *faces, int F, int S,
+                   float blur_radius, int nthreads,
+                   int32_t *pix_to_face, float *zbuf, float *bary, float *dists)
+{
+    rasterize_impl(verts_ndc, faces, F, S, blur_radius, nthreads, 1, pix_to_face, zbuf, bary, dists);
+}
+
+/* the plain loop over all faces for every pixel (what PyTorch3D's CPU rasteriser does) */
+void ref_rasterize_naive(const float *verts_ndc, const int32_t *faces, int F, int S,
+                         float blur_radius, int nthreads,
+                         int32_t *pix_to_face, float *zbuf, float *bary, float *dists)
+{
+    rasterize_impl(verts_ndc, faces, F, S, blur_radius, nthreads, 0, pix_to_face, zbuf, bary, dists);
 }
 
 /* ---------------------------------------------------------------- texture sampling (A.3) */

@@ -41,6 +41,8 @@ def lib():
         _lib.ref_project_verts.argtypes = [F32P, ctypes.c_int, F32P, F32P, ctypes.c_float, F32P]
         _lib.ref_rasterize.argtypes = [F32P, I32P, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int,
                                        I32P, F32P, F32P, F32P]
+        _lib.ref_rasterize_naive.argtypes = _lib.ref_rasterize.argtypes
+        _lib.ref_rasterize_naive.restype = None
         _lib.ref_shade_fwd.argtypes = [I32P, F32P, F32P, F32P, F32P, I32P, F32P, ctypes.c_int, ctypes.c_int, F32P, F32P]
         _lib.ref_shade_bwd.argtypes = [F32P, I32P, F32P, F32P, F32P, F32P, I32P, F32P, ctypes.c_int, ctypes.c_int,
                                        F64P, F32P]
@@ -149,15 +151,17 @@ def project_verts(verts, R, T):
     return out
 
 
-def rasterize(verts_ndc, faces, S, blur_radius=0.0, nthreads=1):
+def rasterize(verts_ndc, faces, S, blur_radius=0.0, nthreads=1, naive=False):
+    """naive=True: every face for every pixel; default: per-row candidate lists (same tests, same results)."""
     verts_ndc = _f32(verts_ndc)
     faces = _i32(faces)
     p2f = np.empty((S, S), np.int32)
     zbuf = np.empty((S, S), np.float32)
     bary = np.empty((S, S, 3), np.float32)
     dists = np.empty((S, S), np.float32)
-    lib().ref_rasterize(_p(verts_ndc, F32P), _p(faces, I32P), faces.shape[0], S, blur_radius, nthreads,
-                        _p(p2f, I32P), _p(zbuf, F32P), _p(bary, F32P), _p(dists, F32P))
+    fn = lib().ref_rasterize_naive if naive else lib().ref_rasterize
+    fn(_p(verts_ndc, F32P), _p(faces, I32P), faces.shape[0], S, blur_radius, nthreads,
+       _p(p2f, I32P), _p(zbuf, F32P), _p(bary, F32P), _p(dists, F32P))
     return p2f, zbuf, bary, dists
 
 

@@ -15,7 +15,8 @@ What it does
     Style_1.jpg at 512x512) into ``assets_*.npz`` so the GPU box, which has no
     /root/reference, can run configs 1/2 on the real mesh.
 
-Usage:  python tests/golden/make_golden.py
+Usage:  python tests/golden/make_golden.py          (G1-G4 + assets, ~1 min)
+        python tests/golden/make_golden.py g5       (G5: 200 reference iterations at 256^2, ~5 min)
 """
 import importlib.util
 import os
@@ -156,9 +157,84 @@ def main():
     im = Image.open(os.path.join(REF, "imgs/Style_1.jpg")).convert("RGB").resize((512, 512), Image.BILINEAR)
     np.savez_compressed(os.path.join(HERE, "assets_style1_512.npz"), rgb_u8=np.asarray(im, dtype=np.uint8))
 
+    # ---- assets for BASELINE configs[3] / configs[4] (teapot: verts/faces only, it ships without UVs or a texture;
+    # bob: 5344 quads -> 10688 fan-triangulated faces, its 2048^2 texture stored at 512^2 -- every run resizes it to
+    # --size anyway, second_approach.py:84-94) and the other style images (Style_3/5 are RGBA: .convert('RGB'))
+    verts, faces, aux = stio.load_obj(os.path.join(REF, "objects/bob_mesh/bob.obj"))
+    tex = list(aux.texture_images.values())[0]
+    t512 = torch.nn.functional.interpolate(tex.permute(2, 0, 1)[None], size=512, mode="bilinear", align_corners=False,
+                                           antialias=True)[0].permute(1, 2, 0)
+    np.savez_compressed(os.path.join(HERE, "assets_bob_mesh.npz"),
+                        verts=verts.numpy(), faces=faces.verts_idx.numpy().astype(np.int32),
+                        verts_uvs=aux.verts_uvs.numpy(), faces_uvs=faces.textures_idx.numpy().astype(np.int32),
+                        texture_u8=(t512.clamp(0, 1) * 255.0).round().to(torch.uint8).numpy())
+    out["bob V/F/VT/tex"] = (tuple(verts.shape), tuple(faces.verts_idx.shape), tuple(aux.verts_uvs.shape), tuple(tex.shape))
+    verts, faces, aux = stio.load_obj(os.path.join(REF, "objects/teapot_mesh/teapot.obj"))
+    assert aux.verts_uvs is None and faces.textures_idx is None and not aux.texture_images
+    np.savez_compressed(os.path.join(HERE, "assets_teapot_mesh.npz"), verts=verts.numpy(),
+                        faces=faces.verts_idx.numpy().astype(np.int32))
+    out["teapot V/F"] = (tuple(verts.shape), tuple(faces.verts_idx.shape))
+    for k, fn in ((3, "Style_3.png"), (4, "Style_4.jpeg"), (5, "Style_5.png")):
+        im = Image.open(os.path.join(REF, "imgs", fn)).convert("RGB").resize((512, 512), Image.BILINEAR)
+        np.savez_compressed(os.path.join(HERE, f"assets_style{k}_512.npz"), rgb_u8=np.asarray(im, dtype=np.uint8))
+
     for k, v in out.items():
         print(k, v)
 
 
+def g5_config1():
+    """G5 = BASELINE.json configs[0]: the reference's own style_transfer() (style_transfer.py:38-85)
+    on cow_mesh + Style_1 at 256x256, 4 views, 200 iterations on the CPU, lr 0.01 (first_approach.py's
+    --style_transfer_lr default), started from the content images (--style_transfer_init content).  Inputs are stored
+    as uint8 so both sides start from bit-identical pixels: the content images are the CPU oracle's renders of the
+    cow (4 seeded random cameras, seed 0) quantised to 8 bits, the style image is Style_1 through PIL at 256x256.
+    The reference's per-step `total_loss` is captured by watching Tensor.backward (the function does not return it).
+    ~5 minutes on 8 cores."""
+    import time
+    from PIL import Image
+    from oracle import render_ref as RR
+    torch.set_num_threads(8)
+    ST, L = import_reference()
+    ST.tqdm = lambda it, **k: it
+    S, B, steps, lr = 256, 4, 200, 0.01
+    cow = np.load(os.path.join(HERE, "assets_cow_mesh.npz"))
+    tex = torch.from_numpy(cow["texture_u8"]).float().div(255.0)
+    tex = torch.nn.functional.interpolate(tex.permute(2, 0, 1)[None], size=S, mode="bilinear",
+                                          align_corners=False)[0].permute(1, 2, 0).contiguous().numpy()
+    g = torch.Generator().manual_seed(0)
+    elev, azim = RR.random_camera_angles(B, lambda k: torch.rand(k, generator=g).numpy())
+    R, T = RR.look_at_view_transform(2.10, elev, azim, at=(0, 0.10, 0.25))
+    imgs, _, _ = RR.render_views(cow["verts"], cow["faces"], cow["verts_uvs"], cow["faces_uvs"], tex, R, T, S, 8)
+    content_u8 = (torch.from_numpy(imgs).clamp(0, 1) * 255.0).round().to(torch.uint8)
+    content = content_u8.float().div(255.0)
+    im = Image.open(os.path.join(REF, "imgs/Style_1.jpg")).convert("RGB").resize((S, S), Image.BILINEAR)
+    style_u8 = torch.from_numpy(np.asarray(im, dtype=np.uint8)).permute(2, 0, 1).contiguous()
+    style = style_u8.float().div(255.0)[None].repeat(B, 1, 1, 1)
+    vgg = P.make_vgg19_features(seed=0)
+    losses = []
+    real_backward = torch.Tensor.backward
+
+    def spy(self, *a, **k):
+        if self.dim() == 0:
+            losses.append(float(self.detach()))
+        return real_backward(self, *a, **k)
+    torch.Tensor.backward = spy
+    t0 = time.time()
+    try:
+        res = ST.style_transfer(content, content, style, vgg, steps=steps, style_weight=1e6, content_weight=1, lr=lr)
+    finally:
+        torch.Tensor.backward = real_backward
+    final = L.compute_perceptual_loss(res.detach(), content, style, vgg)
+    print("G5: %d steps in %.0f s; loss %.6g -> %.6g (after the last update %.6g)" % (steps, time.time() - t0, losses[0],
+                                                                                  losses[-1], float(final)))
+    np.savez_compressed(os.path.join(HERE, "g5_config1_style_transfer.npz"), content_u8=content_u8.numpy(),
+                        style_u8=style_u8.numpy(), R=R, T=T, steps=steps, lr=np.float32(lr),
+                        losses=np.asarray(losses, np.float64), final_loss=np.float64(float(final)),
+                        result_f16=res.detach().numpy().astype(np.float16))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "g5":
+        g5_config1()
+    else:
+        main()

@@ -676,3 +676,83 @@ def test_content_targets_of_alternating_batches_are_kept(mods, vgg, monkeypatch)
     calls.clear()
     changed = L.compute_perceptual_loss(cur, batches[1], sty, vgg).item()
     assert "st3d_plan_set_content" in calls and changed != ref[1]
+
+
+def test_content_target_is_recomputed_for_a_new_tensor_at_a_recycled_address(mods, vgg, monkeypatch, cow, golden_dir, tmp_path):
+    """The target cache must not mistake a NEW content batch for the previous one when the allocator hands it the freed
+    batch's address (libst3d kernels write into fresh buffers, so `_version` is 0 for both): every call with fresh
+    content pays the conv4_2 forward, as the reference's loop with --content_background noise does."""
+    _, L, U, dev = mods
+    import st3d.vgg as V
+    S, B = 64, 2
+    g = torch.Generator().manual_seed(0)
+    cur = torch.rand(B, 3, S, S, generator=g).to(dev)
+    sty = torch.rand(1, 3, S, S, generator=g).to(dev).expand(B, -1, -1, -1)
+    host = [torch.rand(B, 3, S, S, generator=g) for _ in range(4)]
+    m = torch.ones(B, 1, S, S, device=dev)
+    want = []
+    for h in host:
+        c = h.to(dev)
+        vgg.plan(B, S).set_content(c, force=True)
+        want.append(L.compute_perceptual_loss(cur, c, sty, vgg).item())
+    assert len(set(want)) == 4
+    calls = []
+    real = V.call
+    monkeypatch.setattr(V, "call", lambda name, *a: (calls.append(name), real(name, *a))[1])
+    got, ptrs = [], []
+    for h in host:                                   # same alloc / free sequence every iteration, like the CLI loop
+        c = U.apply_background(h.to(dev), m, "style", sty)      # output of a libst3d kernel: fresh buffer, _version 0
+        ptrs.append(c.data_ptr())
+        got.append(L.compute_perceptual_loss(cur, c, sty, vgg).item())
+        del c
+    assert got == want
+    assert calls.count("st3d_plan_set_content") == 4
+    # the shipped CLI with noise backgrounds: one content forward per step
+    import second_approach as SA
+    obj, style = _write_cow_assets(str(tmp_path), cow, golden_dir)
+    calls.clear()
+    SA.main(["--obj_path", obj, "--style_path", style, "--size", "64", "--n_views", "2", "--batch_size", "2", "--epochs", "3",
+             "--output_path", str(tmp_path / "noise"), "--seed", "0", "--content_background", "noise", "--save_every", "0"])
+    assert calls.count("st3d_plan_set_content") == 3, calls
+
+
+def test_get_vgg_loads_a_local_torchvision_state_dict(mods, tmp_path, golden_dir):
+    """The only route to a real stylisation offline: a torchvision-keyed state_dict (`features.<idx>.weight`, what
+    models.vgg19(...).state_dict() holds, utils.py:49) saved locally and loaded through get_vgg(weights=...) /
+    ST3D_VGG19_WEIGHTS / --vgg_weights.  Checked against the oracle VGG carrying the same tensors."""
+    ST, L, U, dev = mods
+    from oracle import perceptual_ref as P
+    state = P.synthetic_vgg19_state(seed=7, bias_scale=0.1)
+    tv_keys = {f"features.{k}": v for k, v in state.items()}
+    tv_keys["classifier.0.weight"] = torch.zeros(4, 4)            # the full torchvision dict has classifier entries too
+    path = str(tmp_path / "vgg19.pth")
+    torch.save(tv_keys, path)
+    model = U.get_vgg(weights=path)
+    ref = P.make_vgg19_features(state)
+    d = np.load(os.path.join(golden_dir, "g3_perceptual.npz"))
+    x = torch.from_numpy(d["cur"])
+    feats = ST.get_features(x.to(dev), model)
+    rf = P.get_features_ref(x, ref)
+    for k in rf:
+        assert float((feats[k].cpu() - rf[k]).abs().max()) <= 2e-4 * float(rf[k].abs().max()), k
+    cur = x.clone().to(dev).requires_grad_(True)
+    loss = L.compute_perceptual_loss(cur, torch.from_numpy(d["con"]).to(dev), torch.from_numpy(d["sty"]).to(dev), model)
+    loss.backward()
+    xr = x.clone().requires_grad_(True)
+    lr = P.perceptual_loss_ref(xr, torch.from_numpy(d["con"]), torch.from_numpy(d["sty"]), ref)
+    lr.backward()
+    assert abs(loss.item() - float(lr.detach())) <= 2e-5 * float(lr.detach())
+    assert float((cur.grad.cpu() - xr.grad).norm() / xr.grad.norm()) <= 1e-4
+    assert abs(loss.item() - float(d["loss"])) > 1e-3 * float(d["loss"])          # really other weights than seed 0
+    # plain '<idx>.weight' keys (a saved `.features` module) and the environment variable
+    torch.save(state, str(tmp_path / "features.pth"))
+    os.environ["ST3D_VGG19_WEIGHTS"] = str(tmp_path / "features.pth")
+    try:
+        m2 = U.get_vgg()
+    finally:
+        del os.environ["ST3D_VGG19_WEIGHTS"]
+    f2 = ST.get_features(x.to(dev), m2)
+    assert torch.equal(f2["conv5_1"], feats["conv5_1"])
+    with pytest.raises(KeyError):
+        torch.save({k: v for k, v in state.items() if not k.startswith("28.")}, str(tmp_path / "bad.pth"))
+        U.get_vgg(weights=str(tmp_path / "bad.pth"))

@@ -479,3 +479,68 @@ def test_soft_shade_forward_and_backward_match_oracle(dev, ops, cow, K, blur, si
     rel_v = float((gverts.cpu().double() - vt.grad).norm() / vt.grad.norm())
     assert rel_t <= (2e-5 if K == 1 else max(2e-5, 2e-7 / gamma)), rel_t
     assert rel_v <= 5e-5, rel_v
+
+
+def _crop_ref(x, y0, x0, h, halo, fn):
+    """fn (a stack of pad-1 convolutions needing `halo` pixels of context) on the crop [y0,y0+h) x [x0,x0+h) of the
+    image x (1,C,S,S): evaluated on the crop + halo clipped to the image -- zero padding at the region edge is the true
+    padding on image borders and only pollutes the halo ring elsewhere."""
+    S = x.shape[-1]
+    ya, xa, yb, xb = max(y0 - halo, 0), max(x0 - halo, 0), min(y0 + h + halo, S), min(x0 + h + halo, S)
+    out = fn(x[:, :, ya:yb, xa:xb].cpu().double())
+    return out[:, :, y0 - ya:y0 - ya + h, x0 - xa:x0 - xa + h]
+
+
+def test_wino_32bit_offset_guard_and_large_images(dev, ops):
+    """The Winograd kernels address one image of the input with 32-bit BYTE offsets: st3d_wino_supported must refuse
+    Cin*H*W*4 >= 2^31 (the plan then runs the direct kernels), and the largest admitted class -- offsets above 2^30
+    bytes -- must still be exact.  64 -> 64 channels at 2048^2 (1 GiB per operand) against an fp64 convolution on
+    crops at the corners, an edge, the middle and the far end of the buffer."""
+    from st3d import _lib
+    lib = _lib.load()
+    assert lib.st3d_wino_supported(64, 64, 2048, 2048) == 1
+    assert lib.st3d_wino_supported(64, 64, 2896, 2896) == 1            # 64*2896^2*4 = 2 147 024 896 < 2^31
+    assert lib.st3d_wino_supported(64, 64, 2900, 2900) == 0
+    assert lib.st3d_wino_supported(64, 64, 4096, 4096) == 0 and lib.st3d_wino_supported(512, 64, 1024, 1024) == 0
+    assert lib.st3d_wino_supported(128, 128, 2048, 2048) == 0           # 2 GiB exactly
+    S, C, h = 2048, 64, 40
+    x = torch.randn((1, C, S, S), generator=torch.Generator(device=dev).manual_seed(0), device=dev)
+    w = torch.randn((C, C, 3, 3), generator=torch.Generator().manual_seed(1)) * 0.05
+    b = torch.randn((C,), generator=torch.Generator().manual_seed(2))
+    uf, ud = ops.wino_pack(w.to(dev))
+    y = ops.wino_fwd(x, uf, b.to(dev), C, relu=False)
+    gx = ops.wino_dgrad(x, None, ud, C)
+    wd = w.double()
+    fwd = lambda t: F.conv2d(t, wd, b.double(), padding=1)
+    bwd = lambda t: F.conv_transpose2d(t, wd, padding=1)               # input-gradient of conv2d(., w, pad 1)
+    for y0, x0 in ((0, 0), (0, S - h), (S - h, 0), (S - h, S - h), (1000, 1004), (S - h, 900)):
+        ref = _crop_ref(x, y0, x0, h, 1, fwd)
+        got = y[:, :, y0:y0 + h, x0:x0 + h].cpu().double()
+        assert float((got - ref).abs().max()) <= 3e-5 * float(ref.abs().max()), (y0, x0)
+        refg = _crop_ref(x, y0, x0, h, 1, bwd)
+        gotg = gx[:, :, y0:y0 + h, x0:x0 + h].cpu().double()
+        assert float((gotg - refg).abs().max()) <= 3e-5 * float(refg.abs().max()), (y0, x0)
+    del y, gx
+    # above the guard the entry points refuse loudly instead of reading garbage
+    with pytest.raises(_lib.St3dError):
+        ops.wino_fwd(torch.empty((1, 64, 2900, 2900), device=dev), uf, None, C)
+
+
+def test_plan_falls_back_to_direct_kernels_above_the_wino_guard(dev):
+    """VGG forward at 2912^2 (conv1_2's input is 64*2912^2*4 B > 2^31): the plan must take the direct kernels for that
+    layer and still match the CPU convolution (crops of conv1_2's post-ReLU tap)."""
+    import style_transfer as ST
+    from st3d import vgg as V
+    S, h = 2912, 20
+    model = V.get_vgg(seed=0, device=dev)
+    x = torch.rand((1, 3, S, S), generator=torch.Generator().manual_seed(0)).to(dev)
+    c12 = ST.get_features(x, model, layers={"2": "c12"})["c12"]
+    assert c12.shape == (1, 64, S, S)
+    st = {k: v.double() for k, v in V.synthetic_state(0).items()}
+    net = lambda t: torch.relu(F.conv2d(torch.relu(F.conv2d(t, st["0.weight"], st["0.bias"], padding=1)), st["2.weight"],
+                                        st["2.bias"], padding=1))
+    for y0, x0 in ((0, 0), (S - h, S - h), (1500, 24), (S - h, 1200)):
+        ref = _crop_ref(x, y0, x0, h, 2, net)
+        got = c12[:, :, y0:y0 + h, x0:x0 + h].cpu().double()
+        assert float((got - ref).abs().max()) <= 5e-5 * float(ref.abs().max()), (y0, x0)
+    del model
