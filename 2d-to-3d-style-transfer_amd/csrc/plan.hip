@@ -144,11 +144,13 @@ struct st3d_plan {
     int last_n;
     // profiling
     bool prof;
-    struct Ev { int fam; hipEvent_t a, b; };
+    struct Ev { int fam, module; hipEvent_t a, b; };
     std::vector<Ev> evs;
     std::vector<hipEvent_t> pool;
     float fam_ms[ST3D_PROFILE_FAMILIES];
     int fam_n[ST3D_PROFILE_FAMILIES];
+    std::vector<int> l_tag;        // per launch since the last read: family * 100 + VGG module index
+    std::vector<float> l_ms;
 };
 
 namespace {
@@ -165,8 +167,8 @@ int dev_alloc(st3d_plan *p, T **ptr, size_t count) {
 }
 
 struct Scope {   // HIP-event bracket around one kernel family (only when profiling is on)
-    st3d_plan *p; int fam; hipStream_t s; hipEvent_t a, b; bool on;
-    Scope(st3d_plan *p_, int fam_, hipStream_t s_) : p(p_), fam(fam_), s(s_), on(p_->prof) {
+    st3d_plan *p; int fam, module; hipStream_t s; hipEvent_t a, b; bool on;
+    Scope(st3d_plan *p_, int fam_, hipStream_t s_, int module_ = 99) : p(p_), fam(fam_), module(module_), s(s_), on(p_->prof) {
         if (!on) return;
         auto get = [&]() {
             hipEvent_t e;
@@ -179,7 +181,7 @@ struct Scope {   // HIP-event bracket around one kernel family (only when profil
     ~Scope() {
         if (!on) return;
         (void)hipEventRecord(b, s);
-        p->evs.push_back({fam, a, b});
+        p->evs.push_back({fam, module, a, b});
     }
 };
 
@@ -201,7 +203,7 @@ int forward(st3d_plan *p, const float *imgs, int n, int upto, bool keep_full, hi
                 return ST3D_E_STATE;
             }
             const bool wino = p->vgg->use_wino && p->vgg->uf[cs] && st3d_wino_supported(Cin, kConvCout[cs], H, W);
-            Scope sc(p, wino ? F_CONV_FWD : F_CONVX_FWD, s);
+            Scope sc(p, wino ? F_CONV_FWD : F_CONVX_FWD, s, m);
             if (wino) {
                 const int pool_m = m + 2;          // conv, relu, pool
                 const int pps = (pool_m <= upto) ? pool_slot(pool_m) : -1;
@@ -222,7 +224,7 @@ int forward(st3d_plan *p, const float *imgs, int n, int upto, bool keep_full, hi
                 Cin = kConvCout[cs];
             }
         } else if (ps >= 0) {
-            Scope sc(p, F_POOL, s);
+            Scope sc(p, F_POOL, s, m);
             ST3D_TRY(st3d_maxpool2x2_fwd(x, p->act[m], p->pidx[ps], n, Cin, H, W, s));
             x = p->act[m];
             H /= 2; W /= 2;
@@ -394,7 +396,7 @@ extern "C" int st3d_plan_loss(st3d_plan *p, const float *current, int n, int bat
         const int m = kStyleTap[i];
         const double C = p->C[m], Hh = p->H[m];
         {
-            Scope sc(p, F_GRAM_FWD, s);
+            Scope sc(p, F_GRAM_FWD, s, m);
             ST3D_TRY(st3d_gram_fwd(p->act[m], n, p->C[m], p->H[m] * p->W[m], p->gram_ws, p->gram_ws_bytes, p->gram[i], s));
         }
         const size_t cc = (size_t)p->C[m] * p->C[m];
@@ -421,7 +423,7 @@ extern "C" int st3d_plan_loss(st3d_plan *p, const float *current, int n, int bat
         for (int i = 0; i < 5; ++i)
             if (kStyleTap[i] == m) st = i;
         if (st >= 0) {
-            Scope sc(p, F_GRAM_BWD, s);
+            Scope sc(p, F_GRAM_BWD, s, m);
             ST3D_TRY(st3d_gram_bwd(p->D[st], p->act[m], n, C, H * W, style_coef[st], have_g ? 1 : 0, g, s));
             have_g = true;
         }
@@ -435,7 +437,7 @@ extern "C" int st3d_plan_loss(st3d_plan *p, const float *current, int n, int bat
         float *dst = (cs == 0) ? grad_current : gn;
         {
             const bool wino = p->vgg->use_wino && p->vgg->ud[cs] && st3d_wino_supported(kConvCout[cs], kConvCin[cs], H, W);
-            Scope sc(p, wino ? F_CONV_DGRAD : F_CONVX_DGRAD, s);
+            Scope sc(p, wino ? F_CONV_DGRAD : F_CONVX_DGRAD, s, m);
             if (g_is_pooled) {
                 if (wino)
                     ST3D_TRY(st3d_wino_dgrad_unpool(g, p->pidx[pool_of_g], p->act[kPoolIdx[pool_of_g]], p->vgg->ud[cs], dst, n,
@@ -465,23 +467,47 @@ extern "C" int st3d_plan_profile(st3d_plan *p, int enable) {
     return ST3D_OK;
 }
 
+static int drain_events(st3d_plan *p);
+
+// per-launch records (family * 100 + VGG module index, milliseconds) gathered since the last call; returns how many
+extern "C" int st3d_plan_profile_launches(st3d_plan *p, int *tags_out, float *ms_out, int capacity, int *count_out) {
+    ST3D_CHECK_ARG(p && count_out && capacity >= 0);
+    ST3D_TRY(drain_events(p));
+    const int n = (int)p->l_tag.size();
+    for (int i = 0; i < n && i < capacity; ++i) {
+        if (tags_out) tags_out[i] = p->l_tag[i];
+        if (ms_out) ms_out[i] = p->l_ms[i];
+    }
+    *count_out = n;
+    if (capacity >= n) { p->l_tag.clear(); p->l_ms.clear(); }
+    return ST3D_OK;
+}
+
 extern "C" int st3d_plan_profile_read(st3d_plan *p, float *ms_out, int *launches_out) {
     ST3D_CHECK_ARG(p);
-    for (auto &e : p->evs) {
-        ST3D_HIP(hipEventSynchronize(e.b));
-        float ms = 0.f;
-        ST3D_HIP(hipEventElapsedTime(&ms, e.a, e.b));
-        p->fam_ms[e.fam] += ms;
-        p->fam_n[e.fam] += 1;
-        p->pool.push_back(e.a);
-        p->pool.push_back(e.b);
-    }
-    p->evs.clear();
+    ST3D_TRY(drain_events(p));
     for (int i = 0; i < ST3D_PROFILE_FAMILIES; ++i) {
         if (ms_out) ms_out[i] = p->fam_ms[i];
         if (launches_out) launches_out[i] = p->fam_n[i];
         p->fam_ms[i] = 0.f;
         p->fam_n[i] = 0;
     }
+    return ST3D_OK;
+}
+
+static int drain_events(st3d_plan *p) {
+    for (auto &e : p->evs) {
+        ST3D_HIP(hipEventSynchronize(e.b));
+        float ms = 0.f;
+        ST3D_HIP(hipEventElapsedTime(&ms, e.a, e.b));
+        p->fam_ms[e.fam] += ms;
+        p->fam_n[e.fam] += 1;
+        p->l_tag.push_back(e.fam * 100 + e.module);
+        p->l_ms.push_back(ms);
+        p->pool.push_back(e.a);
+        p->pool.push_back(e.b);
+    }
+    p->evs.clear();
+    if (p->l_tag.size() > (1u << 20)) { p->l_tag.clear(); p->l_ms.clear(); }      // nobody is reading them
     return ST3D_OK;
 }

@@ -80,8 +80,7 @@ def main(argv=None):
                                                    batch_denom=vb.size)     # image term -> share of the batch mean
                 loss.backward()
             else:
-                loss = torch.zeros((), device=run.device)
-                run.zero_contribution()
+                loss = run.idle_contribution()
             run.optimizer.step()
             shown = run.global_sum(loss).item()
             run.log(f'Batch {vb.index}, Step {step}, Loss {shown}')

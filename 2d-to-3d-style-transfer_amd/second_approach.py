@@ -49,7 +49,7 @@ def main(argv=None):
         for vb in tqdm(list(run.batches()), leave=True, desc="Batch", disable=not run.main):
             run.optimizer.zero_grad()
             if vb.hi == vb.lo:                      # more ranks than views in this batch
-                run.zero_contribution()
+                epoch_loss += run.idle_contribution()
                 run.optimizer.step()
                 continue
             cams = run.cameras[vb.lo:vb.hi]

@@ -84,6 +84,8 @@ SIGNATURES = {
     "st3d_plan_loss": (c_int, [ctypes.c_void_p, c_f32p, c_int, c_int, c_float, c_float, c_f32p, c_f32p, c_stream]),
     "st3d_plan_profile": (c_int, [ctypes.c_void_p, c_int]),
     "st3d_plan_profile_read": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_float), ctypes.POINTER(c_int)]),
+    "st3d_plan_profile_launches": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_float), c_int,
+                                           ctypes.POINTER(c_int)]),
 }
 
 _lib = None

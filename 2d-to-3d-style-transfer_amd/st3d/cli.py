@@ -233,6 +233,21 @@ class Run:
         for p in self.optimizer.params:
             p.grad = torch.zeros_like(p)
 
+    def idle_contribution(self):
+        """This rank has no views in the batch: it still joins the gradient all-reduce, and it still owes its 1/world
+        share of the view-INDEPENDENT terms (the mesh regularisers of 'mesh'/'both' and the optional texture
+        regularisers), which every rank adds with weight 1/world so that the SUM over ranks counts them once.
+        Leaves the gradients in place for ``optimizer.step()`` and returns this rank's (detached) loss share."""
+        import losses as _l
+        self.zero_contribution()
+        mesh = self.current_mesh()
+        total = self.regularisers(None, None, mesh, 0, 1)
+        if self.args.optimization_target in ('mesh', 'both'):
+            total = total + _l._mesh_terms(self.opt['verts'], self.original_verts, mesh, self.loss_weights)
+        if torch.is_tensor(total) and total.requires_grad:
+            total.backward()                      # accumulates into the zero gradients
+        return total.detach() if torch.is_tensor(total) else torch.zeros((), device=self.device)
+
     def global_sum(self, value):
         t = value.detach().clone()
         if self.world > 1:
@@ -272,7 +287,7 @@ class Run:
         ranks (the gradient all-reduce SUMs)."""
         import losses as _l
         a, total = self.args, 0
-        if getattr(a, "tv_weight", 0.0):
+        if getattr(a, "tv_weight", 0.0) and n_local:
             total = total + a.tv_weight * (n_local / batch_size) * _l.compute_tv_loss(current, coverage)
         if getattr(a, "rgb_range_weight", 0.0):
             total = total + (a.rgb_range_weight / self.world) * _l.rgb_range_loss(mesh)

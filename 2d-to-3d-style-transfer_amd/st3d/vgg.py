@@ -238,6 +238,16 @@ class PerceptualPlan:
         return {k: {"ms": ms[i], "launches": nl[i]} for i, k in enumerate(names)}
 
 
+    FAMILIES = ("conv_fwd", "conv_dgrad", "pool", "gram_fwd", "gram_bwd", "elementwise", "convx_fwd", "convx_dgrad")
+
+    def profile_launches(self):
+        """[(family, VGG module index, ms)] for every launch bracket since the last read (profiling on)."""
+        cap = 4096
+        tags, ms, n = (ctypes.c_int * cap)(), (ctypes.c_float * cap)(), ctypes.c_int(0)
+        call("st3d_plan_profile_launches", self._h, tags, ms, cap, ctypes.byref(n))
+        return [(self.FAMILIES[tags[i] // 100], tags[i] % 100, ms[i]) for i in range(min(n.value, cap))]
+
+
 class _DevArray:
     """__cuda_array_interface__ shim so torch can view a raw device pointer without a copy."""
 

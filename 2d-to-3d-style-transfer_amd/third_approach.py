@@ -70,7 +70,7 @@ def main(argv=None):
                                                        batch_denom=vb.size)
                     loss.backward()
                 else:
-                    run.zero_contribution()
+                    loss = run.idle_contribution()
                 run.optimizer.step()
             run.log(f'Round {rnd}, Batch {vb.index}, Loss {run.global_sum(loss).item()}')
         run.maybe_checkpoint(rnd + 1)

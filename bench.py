@@ -15,11 +15,16 @@ region (`--no-hoist` recomputes them every step like the reference does).  Scali
 every rank renders 8 views of the SAME texture, so the job does N*8 views per step;
 `value` counts 8-view iterations per second over the whole job (= steps/s * N).
 
-Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (the Winograd conv launches, ~83 % of
-the step) against the fp32-MFMA peak from HIP events on the launch stream; `step_roofline` prices the whole
-step with the algorithmic flop count of SURVEY.md 8d (396.9 GFLOP per 512^2 view-step, targets hoisted);
-`cpu_baseline` times the CPU restatement (oracle/) of the reference's step on the host cores on a
-bounded sample (1 view) and scales it to the 8-view step.
+Prints ONE JSON line (rank 0).
+  roofline       the dominant kernel (the Winograd conv launches, ~80 % of the step) against the fp32-MFMA peak:
+                 achieved = MFMA flops ISSUED (16 multiplies per 2x2 outputs, i.e. 16/36 of the direct convolution's
+                 count) / HIP-event time on the launch stream, so frac <= 1 by construction; the direct-convolution
+                 equivalent rate is reported separately as alg_equiv_tflops.
+  step_roofline  the same accounting for the whole step (all MFMA flops issued / step time).
+  kernels        per kernel family: ms/step, launches, and either mfma_frac (issued flops / peak) or hbm_frac
+                 (algorithmic bytes of SURVEY.md 8d / time / 8 TB/s) -- whichever roof bounds it.
+  cpu_baseline   the CPU restatement (oracle/) of ONE full reference step (8 views: 16 renders, 3 VGG forwards + 1
+                 backward, texture backward, Adam) timed on the host cores.
 """
 import argparse
 import json
@@ -38,37 +43,64 @@ import torch  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-F_ALG_VIEW_512 = 396.9e9          # VGG fwd 189.35 + dgrad 189.35 + Gram fwd/bwd 2*9.13 GFLOP
 PEAK_FP32_MFMA = 157.3e12         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-# MFMA flops the kernels actually EXECUTE per 512^2 view-step: Winograd F(2x2,3x3) does
-# 16/36 of the direct-convolution multiplies for every layer but conv1_1 (direct: K padded 3->4 forward,
-# M padded 3->32 in the input-gradient), the Gram forward computes only tiles on/above the diagonal.
-F_EXEC_VIEW_512 = (0.906 * 4 / 3 + (189.35 - 0.906) * 16 / 36) * 1e9 \
-    + (0.906 * 32 / 3 + (189.35 - 0.906) * 16 / 36) * 1e9 \
-    + (2.147 + 2.147 + 2.147 * 3 / 4 + 2.147 * 10 / 16 + 0.537 * 10 / 16) * 1e9 + 9.13e9
+PEAK_HBM = 8.0e12                 # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+
+# torchvision vgg19().features conv modules up to conv5_1: (module index, Cin, Cout, resolution divisor)
+CONVS = [(0, 3, 64, 1), (2, 64, 64, 1), (5, 64, 128, 2), (7, 128, 128, 2), (10, 128, 256, 4), (12, 256, 256, 4),
+         (14, 256, 256, 4), (16, 256, 256, 4), (19, 256, 512, 8), (21, 512, 512, 8), (23, 512, 512, 8), (25, 512, 512, 8),
+         (28, 512, 512, 16)]
+STYLE_TAPS = {0: (64, 1), 5: (128, 2), 10: (256, 4), 19: (512, 8), 28: (512, 16)}      # module -> (C, divisor)
 
 
-def load_assets(size, device):
-    cow = np.load(os.path.join(GOLDEN, "assets_cow_mesh.npz"))
-    sty = np.load(os.path.join(GOLDEN, "assets_style1_512.npz"))["rgb_u8"]
-    verts = torch.from_numpy(cow["verts"]).to(device)
-    faces = torch.from_numpy(cow["faces"].astype(np.int64)).to(device)
-    verts_uvs = torch.from_numpy(cow["verts_uvs"])[None].to(device)
-    faces_uvs = torch.from_numpy(cow["faces_uvs"].astype(np.int64))[None].to(device)
-    tex = torch.from_numpy(cow["texture_u8"]).to(torch.float32).div(255.0)[None].to(device)
-    # second_approach.py:84-94: texture resized to size x size (bilinear, align_corners=False)
-    tex = F.interpolate(tex.permute(0, 3, 1, 2), size=size, mode="bilinear", align_corners=False).permute(0, 2, 3, 1).contiguous()
+def conv_alg_flops(module, S, B):
+    """2*9*Cin*Cout flop per output pixel -- one direction (forward or input-gradient)."""
+    for m, cin, cout, d in CONVS:
+        if m == module:
+            return 2.0 * 9 * cin * cout * (S // d) ** 2 * B
+    return 0.0
+
+
+def gram_alg_flops(module, S, B):
+    C, d = STYLE_TAPS[module]
+    return 2.0 * C * C * (S // d) ** 2 * B
+
+
+def gram_fwd_issued_fraction(module):
+    """The forward computes only 128x128 tiles on/above the diagonal (gram.hip)."""
+    C = STYLE_TAPS[module][0]
+    t = max(C // 128, 1)
+    return (t * (t + 1) / 2) / (t * t)
+
+
+def load_assets(size, device, mesh="cow", style_k=1):
+    d = np.load(os.path.join(GOLDEN, f"assets_{mesh}_mesh.npz"))
+    sty = np.load(os.path.join(GOLDEN, f"assets_style{style_k}_512.npz"))["rgb_u8"]
+    verts = torch.from_numpy(d["verts"]).to(device)
+    faces = torch.from_numpy(d["faces"].astype(np.int64)).to(device)
+    if "verts_uvs" in d.files:
+        verts_uvs = torch.from_numpy(d["verts_uvs"])[None].to(device)
+        faces_uvs = torch.from_numpy(d["faces_uvs"].astype(np.int64))[None].to(device)
+        tex = torch.from_numpy(d["texture_u8"]).to(torch.float32).div(255.0)[None].to(device)
+        # second_approach.py:84-94: texture resized to size x size (bilinear, align_corners=False)
+        tex = F.interpolate(tex.permute(0, 3, 1, 2), size=size, mode="bilinear", align_corners=False).permute(0, 2, 3, 1).contiguous()
+    else:                            # teapot: no UVs / texture in the reference's data (SURVEY.md D3)
+        from st3d import io as stio
+        verts_uvs = stio.synthesize_uvs(verts.cpu())[None].to(device)
+        faces_uvs = faces[None].clone()
+        noise = torch.randn((size, size, 3), generator=torch.Generator().manual_seed(0))
+        tex = (0.5 + 0.1 * noise).clamp(0, 1)[None].to(device)
     style = torch.from_numpy(sty).permute(2, 0, 1).to(torch.float32).div(255.0)
     if size != style.shape[1]:
-        style = F.interpolate(style[None], size=size, mode="bilinear", align_corners=False, antialias=True)[0]
+        style = F.interpolate(style[None], size=size, mode="bilinear", align_corners=False, antialias=size < style.shape[1])[0]
     return verts, faces, verts_uvs, faces_uvs, tex, style.contiguous().to(device)
 
 
-def cpu_baseline(size, seed_cam):
-    """CPU restatement of ONE view of the reference step, as the reference executes it
-    (second_approach.py:157-189: content render + current render, compute_perceptual_loss = 3 VGG
-    forwards + 1 backward, texture backward, Adam), on the host cores; scaled to 8 views."""
-    from oracle import perceptual_ref as P
+def cpu_baseline(size, views, seed_cam):
+    """CPU restatement (oracle/loop_ref.py) of ONE step of the reference loop as the reference executes it
+    (second_approach.py:157-189): `views` content renders + `views` current renders (naive rasteriser, OpenMP over
+    rows), compute_perceptual_loss = 3 VGG-19 forwards + 1 backward on torch-CPU fp32, texture backward, Adam."""
+    from oracle import loop_ref as LR
     from oracle import render_ref as RR
     cores = os.cpu_count() or 1
     threads = min(cores, 64)
@@ -81,46 +113,50 @@ def cpu_baseline(size, seed_cam):
     if size != style.shape[2]:
         style = F.interpolate(style, size=size, mode="bilinear", align_corners=False, antialias=True)
     g = torch.Generator().manual_seed(seed_cam)
-    elev, azim = RR.random_camera_angles(1, lambda k: torch.rand(k, generator=g).numpy())
+    elev, azim = RR.random_camera_angles(views, lambda k: torch.rand(k, generator=g).numpy())
     R, T = RR.look_at_view_transform(2.10, elev, azim, at=(0, 0.10, 0.25))
-    model = P.make_vgg19_features(seed=0)
-    m = np.zeros_like(tex); v = np.zeros_like(tex)
 
-    def one_view_step():
-        content, _, _ = RR.render_views(cow["verts"], cow["faces"], cow["verts_uvs"], cow["faces_uvs"], tex, R, T, size, threads)
-        cur, _, frags = RR.render_views(cow["verts"], cow["faces"], cow["verts_uvs"], cow["faces_uvs"], tex, R, T, size, threads)
-        cur_t = torch.from_numpy(cur).requires_grad_(True)
-        loss = P.perceptual_loss_ref(cur_t, torch.from_numpy(content), style, model)
-        loss.backward()
-        gt = RR.shade_bwd(cur_t.grad.numpy()[0], frags[0], cow["verts_uvs"], cow["faces_uvs"], tex).astype(np.float32)
-        RR.adam_step(tex, gt, m, v, 1)
-        return float(loss)
-
-    one_view_step()                       # warm-up (page-in, MKL threads)
+    def loop(n):
+        return LR.SecondApproachRef(cow["verts"], cow["faces"], cow["verts_uvs"], cow["faces_uvs"], tex, R[:n], T[:n], size,
+                                    style, target="texture", lr=0.01, nthreads=threads, hoist=False)
+    loop(1).step()                        # warm-up on one view (page-in, MKL/OpenMP thread pools)
+    ref = loop(views)
     t0 = time.time()
-    reps = 0
-    while reps < 2 or time.time() - t0 < 10.0:
-        one_view_step()
-        reps += 1
-        if time.time() - t0 > 40.0:
-            break
-    t_view = (time.time() - t0) / reps
-    return {"value": 1.0 / (8.0 * t_view), "unit": "iter/s (8 views, %dx%d)" % (size, size), "cores": threads,
-            "kind": "port",
-            "sample": "%d x one-view step (%.2f s each: 2 naive renders with %d OpenMP threads, 3 VGG-19 forwards + 1 "
-                      "backward on torch-CPU fp32, texture backward, Adam), scaled x8 views" % (reps, t_view, threads)}
+    loss = ref.step()
+    t_step = time.time() - t0
+    return {"value": round(1.0 / t_step * (views / 8.0), 5), "unit": "iter/s (8 views, %dx%d)" % (size, size), "cores": threads,
+            "kind": "port", "seconds_per_step": round(t_step, 2), "loss": loss,
+            "sample": "ONE full %d-view step of the CPU restatement (oracle/loop_ref.py: %d naive renders with %d OpenMP "
+                      "threads, 3 VGG-19 forwards + 1 backward on torch-CPU fp32 with %d threads, texture backward, Adam), "
+                      "%.1f s, after a 1-view warm-up step; the reference additionally runs the unused VGG tail (modules "
+                      "29-36, +7 %% flops) in each forward" % (views, 2 * views, threads, threads, t_step)}
+
+
+def time_ms(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    b.synchronize()
+    return a.elapsed_time(b) / reps
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--views", type=int, default=8, help="views per GPU per step")
+    ap.add_argument("--mesh", choices=["cow", "bob", "teapot"], default="cow")
+    ap.add_argument("--style", type=int, choices=[1, 3, 4, 5], default=1)
     ap.add_argument("--no-hoist", action="store_true", help="recompute content renders + VGG targets every step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-kernels", action="store_true", help="extra untimed steps with per-kernel-family HIP events")
+    ap.add_argument("--profile-kernels", action="store_true", help="per-kernel HIP events also when --gpus > 1")
+    ap.add_argument("--layers", action="store_true", help="add the per-layer table to the JSON line")
     ap.add_argument("--target", choices=["texture", "mesh", "both"], default="texture",
                     help="optimization_target (BASELINE configs[1] = texture; configs[4] = both)")
     args = ap.parse_args()
@@ -143,12 +179,13 @@ def main():
     import style_transfer as ST
     import utils as U
     U.device = ST.device = L.device = device
+    from st3d import ops
     from st3d.render import (AmbientLights, FoVPerspectiveCameras, MeshRasterizer, MeshRenderer, RasterizationSettings,
                              SoftPhongShader)
 
     S, Bv = args.size, args.views
     global_views = Bv * world
-    verts, faces, verts_uvs, faces_uvs, tex, style_image = load_assets(S, device)
+    verts, faces, verts_uvs, faces_uvs, tex, style_image = load_assets(S, device, args.mesh, args.style)
     content_mesh = U.build_mesh(verts_uvs, faces_uvs, tex, verts, faces)
     cams0 = FoVPerspectiveCameras(device=device)
     renderer = MeshRenderer(MeshRasterizer(cams0, RasterizationSettings(image_size=S, blur_radius=0.0, faces_per_pixel=1)),
@@ -192,122 +229,207 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         loss = step()
-    ev1.record()
+        marks[i + 1].record()
     barrier()
     elapsed = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)
+    dev_ms = marks[0].elapsed_time(marks[-1])
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = per_step[len(per_step) // 2]
     final_loss = float(loss.detach())
+    allreduce_ms = None
     if world > 1:
-        t = torch.tensor([elapsed, dev_ms], device=device, dtype=torch.float64)
+        # the one collective of the step, timed on its own right after the timed region (same tensor size, same stream)
+        g = torch.zeros_like(texture_map)
+        allreduce_ms = time_ms(lambda: torch.distributed.all_reduce(g), reps=20, warm=3)
+        t = torch.tensor([elapsed, dev_ms, median_ms, allreduce_ms], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed, dev_ms = float(t[0]), float(t[1])
+        elapsed, dev_ms, median_ms, allreduce_ms = (float(x) for x in t)
         lt = torch.tensor([final_loss], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(lt)
         final_loss = float(lt[0])
 
-    kernels = None
+    kernels, layers = None, None
     nprof = 5
+    wino = os.environ.get("ST3D_CONV") != "direct"
     if args.profile_kernels or world == 1:
-        # per-kernel-family HIP events (recorded by libst3d on the stream the kernels are launched on) over nprof
-        # further steps of the same loop, right after the timed region
+        # per-launch HIP events (recorded by libst3d on the stream the kernels are launched on) over nprof further
+        # steps of the same loop, right after the timed region
         plan = vgg.plan(Bv, S)
         plan.profile(True)
         for _ in range(nprof):
             step()
         torch.cuda.synchronize()
-        pr = plan.profile_read()
+        launches = plan.profile_launches()
+        plan.profile_read()
         plan.profile(False)
-        s2 = (S / 512.0) ** 2
-        wino = os.environ.get("ST3D_CONV") != "direct"
-        f_conv = (189.35e9 - 0.906e9 if wino else 189.35e9) * s2 * Bv
-        flops = {"conv_fwd": f_conv, "conv_dgrad": f_conv, "convx_fwd": 0.906e9 * s2 * Bv if wino else 0.0,
-                 "convx_dgrad": 0.906e9 * s2 * Bv if wino else 0.0, "gram_fwd": 9.13e9 * s2 * Bv, "gram_bwd": 9.13e9 * s2 * Bv}
-        kernels = {}
-        for k, v in pr.items():
-            ms = v["ms"] / nprof
-            kernels[k] = {"ms_per_step": round(ms, 4), "launches_per_step": v["launches"] // nprof}
-            if flops.get(k) and ms > 0:
-                kernels[k]["alg_tflops"] = round(flops[k] / (ms * 1e-3) / 1e12, 2)
-                kernels[k]["alg_frac_of_peak"] = round(flops[k] / (ms * 1e-3) / PEAK_FP32_MFMA, 4)
+        agg = {}
+        for fam, module, ms in launches:
+            e = agg.setdefault((fam, module), [0.0, 0])
+            e[0] += ms
+            e[1] += 1
+        kernels, layers = {}, []
+        for (fam, module), (ms, n) in sorted(agg.items()):
+            ms /= nprof
+            k = kernels.setdefault(fam, {"ms_per_step": 0.0, "launches_per_step": 0, "_issued": 0.0, "_alg": 0.0, "_bytes": 0.0})
+            k["ms_per_step"] += ms
+            k["launches_per_step"] += n // nprof
+            issued = alg = nbytes = 0.0
+            hw4 = lambda c, d: 4.0 * c * (S // d) ** 2 * Bv          # bytes of a (Bv, c, S/d, S/d) fp32 tensor
+            if fam in ("conv_fwd", "conv_dgrad"):
+                alg = conv_alg_flops(module, S, Bv)
+                issued = alg * (16.0 / 36.0)
+            elif fam in ("convx_fwd", "convx_dgrad") and module == 0:
+                alg = conv_alg_flops(0, S, Bv)
+                # conv1_1 on the vector ALU: HBM-bound.  fwd reads 3 + writes 64 channels; dgrad reads the gradient and the
+                # ReLU gate (64 + 64) and writes 3
+                nbytes = hw4(3 + 64, 1) if fam == "convx_fwd" else hw4(64 + 64 + 3, 1)
+            elif fam in ("convx_fwd", "convx_dgrad"):
+                alg = issued = conv_alg_flops(module, S, Bv)          # direct MFMA kernels (ST3D_CONV=direct, odd shapes)
+            elif fam == "gram_fwd":
+                alg = gram_alg_flops(module, S, Bv)
+                issued = alg * gram_fwd_issued_fraction(module)
+            elif fam == "gram_bwd":
+                alg = issued = gram_alg_flops(module, S, Bv)
+                C, d = STYLE_TAPS[module]
+                nbytes = hw4(C, d) * (2 if module == 28 else 3)      # read F, (read +) write dF: conv5_1 stores, the rest accumulate
+            k["_issued"] += issued
+            k["_alg"] += alg
+            k["_bytes"] += nbytes
+            row = {"family": fam, "module": module, "ms": round(ms, 4)}
+            if issued:
+                row["mfma_frac"] = round(issued / (ms * 1e-3) / PEAK_FP32_MFMA, 4)
+            if nbytes:
+                row["hbm_frac"] = round(nbytes / (ms * 1e-3) / PEAK_HBM, 4)
+            layers.append(row)
+        for fam, k in kernels.items():
+            ms = k["ms_per_step"]
+            k["ms_per_step"] = round(ms, 4)
+            issued, alg, nbytes = k.pop("_issued"), k.pop("_alg"), k.pop("_bytes")
+            if ms > 0 and issued:
+                k["issued_tflops"] = round(issued / (ms * 1e-3) / 1e12, 2)
+                k["mfma_frac"] = round(issued / (ms * 1e-3) / PEAK_FP32_MFMA, 4)
+                k["alg_equiv_tflops"] = round(alg / (ms * 1e-3) / 1e12, 2)
+            if ms > 0 and nbytes:
+                k["alg_gbps"] = round(nbytes / (ms * 1e-3) / 1e9, 1)
+                k["hbm_frac"] = round(nbytes / (ms * 1e-3) / PEAK_HBM, 4)
+        # the HBM/latency-bound kernels outside the VGG plan, each timed alone on this rank's inputs (torch events on the
+        # current stream, which is the stream libst3d launches them on); algorithmic bytes per SURVEY.md 8d
+        with torch.no_grad():
+            mesh = U.build_mesh(out["verts_uvs"], out["faces_uvs"], texture_map, out["verts"], out["faces"])
+            f32 = mesh.faces_i32()
+            fuv = mesh.textures.faces_uvs_i32()
+            vuv = out["verts_uvs"][0].contiguous()
+            tex2 = texture_map.detach()[0].contiguous()
+            Fn, px = f32.shape[0], Bv * S * S
+            ndc = ops.project_verts(out["verts"].detach(), my_cams.R, my_cams.T)
+            frag = ops.raster_fwd(ndc, f32, S)
+            gimg = torch.randn((Bv, 3, S, S), device=device)
+            st = optimizer._state_of(texture_map) if texture_map in optimizer.params else None
+            hb = {
+                "raster_fwd": (time_ms(lambda: ops.raster_fwd(ndc, f32, S)), Bv * Fn * 52.0 + px * 24.0),
+                "shade_fwd": (time_ms(lambda: ops.shade_fwd(frag, vuv, fuv, tex2)), px * (24.0 + 16.0)),
+                "shade_bwd_texture_scatter": (time_ms(lambda: ops.shade_bwd(gimg, frag, vuv, fuv, tex2)), px * (24.0 + 12.0) + 2 * tex2.numel() * 4.0),
+            }
+            if st is not None:
+                gdummy = torch.zeros_like(tex2)
+                pdummy, m1, m2 = tex2.clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone()
+                hb["adam"] = (time_ms(lambda: ops.adam_step(pdummy, gdummy, m1, m2, 3, 0.01)), 7.0 * tex2.numel() * 4.0)
+        for name, (ms, nbytes) in hb.items():
+            kernels[name] = {"ms_per_call": round(ms, 4), "alg_gbps": round(nbytes / (ms * 1e-3) / 1e9, 1),
+                             "hbm_frac": round(nbytes / (ms * 1e-3) / PEAK_HBM, 4), "timed": "standalone, %d views" % Bv}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         s2 = (S / 512.0) ** 2
-        wino = os.environ.get("ST3D_CONV") != "direct"
-        f_alg_step = F_ALG_VIEW_512 * s2 * Bv + (0 if not args.no_hoist else 145.86e9 * s2 * Bv)
-        f_exec_step = F_EXEC_VIEW_512 * s2 * Bv if wino else f_alg_step
+        # algorithmic and issued MFMA flops of one step on this GPU
+        f_alg_step = sum(conv_alg_flops(m, S, Bv) for m, *_ in CONVS) * 2 + sum(gram_alg_flops(m, S, Bv) for m in STYLE_TAPS) * 2
+        if args.no_hoist:
+            f_alg_step += sum(conv_alg_flops(m, S, Bv) for m, *_ in CONVS if m <= 21)
+        f_wino_alg = sum(conv_alg_flops(m, S, Bv) for m, *_ in CONVS if m != 0) * 2
+        f_issued_step = (f_wino_alg * (16.0 / 36.0) if wino else f_wino_alg + 2 * conv_alg_flops(0, S, Bv)) \
+            + sum(gram_alg_flops(m, S, Bv) * (gram_fwd_issued_fraction(m) + 1.0) for m in STYLE_TAPS)
         step_s = dev_ms / args.steps * 1e-3
-        std_cfg = S == 512 and Bv == 8 and not args.no_hoist and wino
-        traffic = {}
-        import glob
-        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))     # newest round last
-        tpath = tfiles[-1] if tfiles else ""
-        if tpath and std_cfg:
-            with open(tpath) as fh:
-                traffic = json.load(fh)
+        std_cfg = S == 512 and Bv == 8 and not args.no_hoist and wino and args.mesh == "cow" and args.target == "texture"
+        traffic, tpath = {}, ""
+        if std_cfg:
+            import glob
+            tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))     # newest round last
+            if tfiles:
+                tpath = tfiles[-1]
+                with open(tpath) as fh:
+                    traffic = json.load(fh)
+        tsrc = ("committed rocprofv3 PMC passes %s (FETCH_SIZE raw + WRITE_SIZE per launch; gfx950 under-reports 16-B/lane "
+                "read streams by up to 2x), not re-measured in this run" % os.path.relpath(tpath, ROOT)) if traffic else None
         step_roofline = {
-            "bound": "mfma", "achieved": round(f_alg_step / step_s / 1e12, 3), "peak": PEAK_FP32_MFMA / 1e12, "unit": "TFLOP/s",
-            "frac": round(f_alg_step / step_s / PEAK_FP32_MFMA, 4),
-            "executed": round(f_exec_step / step_s / 1e12, 3), "executed_frac": round(f_exec_step / step_s / PEAK_FP32_MFMA, 4),
+            "bound": "mfma", "achieved": round(f_issued_step / step_s / 1e12, 3), "peak": PEAK_FP32_MFMA / 1e12, "unit": "TFLOP/s",
+            "frac": round(f_issued_step / step_s / PEAK_FP32_MFMA, 4),
+            "alg_equiv_tflops": round(f_alg_step / step_s / 1e12, 3),
             "traffic": (traffic["fetch_bytes_raw_per_step"] + traffic["write_bytes_per_step"]) if traffic else None,
-            "note": "whole step per GPU (renders, losses, Adam and host gaps included): algorithmic flops of the direct "
-                    "convolutions + Grams (%.1f GF/step, SURVEY 8d) over the HIP-event time of the timed region (%.3f ms/step)"
-                    % (f_alg_step / 1e9, dev_ms / args.steps)}
+            "traffic_source": tsrc,
+            "note": "whole step per GPU (renders, losses, Adam and host gaps included): MFMA flops issued per step (%.1f GF: "
+                    "Winograd convs 16/36 of the direct count, Gram forward upper tiles only) over the HIP-event time of the "
+                    "timed region (%.3f ms/step); alg_equiv_tflops prices the same time with the direct-convolution count of "
+                    "SURVEY.md 8d (%.1f GF/step)" % (f_issued_step / 1e9, dev_ms / args.steps, f_alg_step / 1e9)}
         roofline = step_roofline
         if kernels and kernels.get("conv_fwd", {}).get("ms_per_step", 0) > 0 and kernels.get("conv_dgrad", {}).get("ms_per_step", 0) > 0:
             # the dominant kernel: the Winograd conv launches (forward + input-gradient), priced together
             kms = kernels["conv_fwd"]["ms_per_step"] + kernels["conv_dgrad"]["ms_per_step"]
             kn = kernels["conv_fwd"]["launches_per_step"] + kernels["conv_dgrad"]["launches_per_step"]
-            f_conv_alg = 2 * ((189.35e9 - 0.906e9) if wino else 189.35e9) * s2 * Bv
-            f_conv_exec = f_conv_alg * (16.0 / 36.0 if wino else 1.0)
+            f_conv_alg = f_wino_alg if wino else f_wino_alg
+            f_conv_issued = f_conv_alg * (16.0 / 36.0 if wino else 1.0)
             ktraffic = None
             if traffic and kn == traffic.get("wino_kernel_launches_per_step"):
                 ktraffic = (traffic["wino_fetch_bytes_raw_per_step"] + traffic["wino_write_bytes_per_step"]) / kn
             roofline = {
-                "bound": "mfma", "achieved": round(f_conv_alg / (kms * 1e-3) / 1e12, 3), "peak": PEAK_FP32_MFMA / 1e12,
-                "unit": "TFLOP/s", "frac": round(f_conv_alg / (kms * 1e-3) / PEAK_FP32_MFMA, 4),
-                "traffic": ktraffic,
-                "executed": round(f_conv_exec / (kms * 1e-3) / 1e12, 3),
-                "executed_frac": round(f_conv_exec / (kms * 1e-3) / PEAK_FP32_MFMA, 4),
+                "bound": "mfma", "achieved": round(f_conv_issued / (kms * 1e-3) / 1e12, 3), "peak": PEAK_FP32_MFMA / 1e12,
+                "unit": "TFLOP/s", "frac": round(f_conv_issued / (kms * 1e-3) / PEAK_FP32_MFMA, 4),
+                "traffic": ktraffic, "traffic_source": tsrc if ktraffic else None,
+                "alg_equiv_tflops": round(f_conv_alg / (kms * 1e-3) / 1e12, 3),
                 "kernel": "wino_kernel<MODE,EPI> (csrc/wino.hip)" if wino else "conv3x3_kernel (csrc/conv.hip)",
                 "launches_per_step": kn, "avg_launch_ms": round(kms / kn, 4), "ms_per_step": round(kms, 4),
                 "share_of_step": round(kms / (dev_ms / args.steps), 4),
-                "note": "achieved = ALGORITHMIC flops of the direct 3x3 convolutions these launches replace (2*9*Cin*Cout per "
-                        "output pixel, forward + input-gradient of every VGG conv but conv1_1: %.1f GF/step = %.2f GF per "
-                        "launch on average) / their HIP-event time, measured on the launch stream over %d steps after the timed "
-                        "region.  It exceeds the fp32 MFMA peak because the kernel is Winograd F(2x2,3x3): 16 instead of 36 "
-                        "multiplies per 2x2 outputs, still fp32 products + fp32 accumulation.  executed = MFMA flops actually "
-                        "issued (16/36 of the algorithmic count) = matrix-pipe utilisation.  traffic = HBM bytes per launch "
-                        "(average) from the committed PMC passes %s (FETCH_SIZE raw + WRITE_SIZE; "
-                        "gfx950 under-reports 16-B/lane read streams by up to 2x), not re-measured live."
-                        % (f_conv_alg / 1e9, f_conv_alg / 1e9 / kn, nprof, os.path.relpath(tpath, ROOT) if tpath else "(none)")}
+                "flops_per_launch_issued": round(f_conv_issued / kn), "flops_per_launch_alg": round(f_conv_alg / kn),
+                "note": "achieved = MFMA flops ISSUED by these launches (Winograd F(2x2,3x3): 16 multiplies per 2x2 outputs = "
+                        "16/36 of the 2*9*Cin*Cout per output pixel of the direct convolutions they replace, forward + "
+                        "input-gradient of every VGG conv but conv1_1: %.1f GF issued, %.1f GF algorithmic per step) / their "
+                        "HIP-event time on the launch stream over %d steps after the timed region; frac = matrix-pipe "
+                        "utilisation.  alg_equiv_tflops = the direct-convolution count over the same time (may exceed the "
+                        "peak; it is not a roofline fraction)." % (f_conv_issued / 1e9, f_conv_alg / 1e9, nprof)}
         tgt = {"texture": "texture-only optimisation", "mesh": "vertex optimisation", "both": "joint vertex + texture optimisation"}[args.target]
+        cfg_name = "BASELINE.json configs[1]" if std_cfg else "variant of BASELINE.json configs[1]"
         res = {
             "metric": "style-transfer iters/sec (512x512, 8 views, cow_mesh)",
             "value": round(args.steps * world * (Bv / 8.0) / elapsed, 4),
             "unit": "iter/s (one iter = 8 views of %dx%d: render + VGG-19 fwd/bwd + Gram/content loss + Adam)" % (S, S),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic views (seeded cameras) of cow_mesh + Style_1 fixtures; "
-                                                            "seeded He-normal VGG-19 weights (pretrained weights need a download)",
-            "config": {"workload": "BASELINE.json configs[1]: cow_mesh + Style_1, %dx%d, %d views/GPU/iter, %s "
-                                   "(second_approach loop body)" % (S, S, Bv, tgt),
+            "ms_per_step": round(ms_per_step, 3), "median_ms_per_step": round(median_ms, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic views (seeded cameras) of %s_mesh + Style_%d fixtures; seeded He-normal VGG-19 weights "
+                    "(pretrained weights need a download)" % (args.mesh, args.style),
+            "config": {"workload": "%s: %s_mesh + Style_%d, %dx%d, %d views/GPU/iter, %s (second_approach loop body)"
+                                   % (cfg_name, args.mesh, args.style, S, S, Bv, tgt),
                        "global_views_per_step": global_views, "texture": "%dx%d" % (S, S),
-                       "targets_hoisted": not args.no_hoist, "parallelism": "views sharded dp%d, RCCL all-reduce of the texture gradient" % world},
+                       "targets_hoisted": not args.no_hoist,
+                       "parallelism": "views sharded dp%d, RCCL all-reduce of the texture gradient" % world},
             "final_loss": final_loss,
             "roofline": roofline,
             "step_roofline": step_roofline,
         }
+        if allreduce_ms is not None:
+            res["allreduce_ms"] = round(allreduce_ms, 4)
+            res["allreduce_bytes"] = int(texture_map.numel() * 4)
         if kernels:
             res["kernels"] = kernels
+        if layers and args.layers:
+            res["layers"] = layers
         if not args.no_cpu_baseline and world == 1:
             try:
-                res["cpu_baseline"] = cpu_baseline(S, 0)
+                res["cpu_baseline"] = cpu_baseline(S, Bv, 0)
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 res["cpu_baseline"] = {"value": None, "error": repr(e)}
         print(json.dumps(res))

@@ -263,6 +263,11 @@ int st3d_plan_loss(st3d_plan *plan, const float *current, int n, int batch_denom
 int st3d_plan_profile(st3d_plan *plan, int enable);
 int st3d_plan_profile_read(st3d_plan *plan, float *ms_out /*host [ST3D_PROFILE_FAMILIES]*/,
                            int *launches_out /*host [ST3D_PROFILE_FAMILIES]*/);
+/* Per-launch records gathered while profiling was on, since the previous call: tag = family * 100 + the VGG module
+ * index the launch belongs to (99 = none), HIP-event milliseconds.  *count_out = records available; they are consumed
+ * when `capacity` holds them all. */
+int st3d_plan_profile_launches(st3d_plan *plan, int *tags_out /*host [capacity]*/, float *ms_out /*host [capacity]*/,
+                               int capacity, int *count_out);
 
 #ifdef __cplusplus
 }
