@@ -61,6 +61,7 @@ struct WinoArgs {
     float *yp;            // EPI 1: pooled output (N,Cout,H/2,W/2)
     uint8_t *yidx;        // EPI 1: argmax
     int N, Cin, Cout, H, W, relu, tiles_x, tiles_y, n_ct;
+    int tiles_per_xcd;    // wino4_kernel: pixel tiles owned by one XCD
     unsigned long long *dbg;   // diagnostic builds only (DBG != 0): per-wave phase cycle sums
 };
 
@@ -418,6 +419,307 @@ __global__ __launch_bounds__(NT, 2) void wino_kernel(const WinoArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// wino4_kernel: the same algorithm on a HALF-SIZE workgroup -- 256 threads = 4 waves, 64 cout x 32 tiles (4 x 32
+// pixels) -- so that TWO workgroups share a CU (2 waves per SIMD as before, 32 KB of LDS each).  They are independent:
+// one's prologue (two dependent HBM round trips) and epilogue (LDS exchange + stores) run under the other's MFMA loop,
+// which the single 512-thread workgroup per CU of wino_kernel cannot do (28 % of a tile's time on the 8-stage Cin = 64
+// layers).  Wave w accumulates row a = w of the 4x4 Winograd domain for BOTH 32-cout halves over ONE 32-tile MFMA
+// n-tile: 2 (halves) x 4 (b) = 8 MFMA tiles = 128 accumulator VGPRs.  Every B operand (V = B^T d B, computed by the lane
+// from the staged patch) now feeds two MFMAs instead of one, halving the VALU + LDS-read work per MFMA; the price is
+// twice the A-operand (U) loads per MFMA (4 dwordx4 per 16 MFMAs) and a 1.59x instead of 1.33x halo on the patch.
+// Same pack layout (pack-waves a and a + 4 are this wave's two halves), same gates, same epilogue algebra.
+constexpr int T4_ROWS = 4, T4_COLS = 32;
+constexpr int NT4 = 256;
+constexpr int PR4 = T4_ROWS + 2;                  // 6 patch rows
+constexpr int PS4 = PR4 * PCP;                    // 288 floats per channel
+constexpr int P4_STAGE = KS * PS4 + 8;            // 2312 floats per stage
+constexpr int EX4_FLOATS = 2 * 4 * 64 * 32;       // [2 j][4 a][64 co][32 tiles]
+constexpr int SMEM4_FLOATS = EX4_FLOATS > 3 * P4_STAGE ? EX4_FLOATS : 3 * P4_STAGE;      // 64 KB: two workgroups per CU use 128 of its 160 KB
+
+template <int MODE, int EPI, int DBG = 0>
+__global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[SMEM4_FLOATS];
+    float *sP = smem;                          // [3][KS][PR4][PCP]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wa = tid >> 6;  // wave = row a of the Winograd domain
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    // grid (XCD-aware, see launch_wino4): blocks are dealt round-robin over the 8 XCDs, so bid & 7 names the XCD.  Each
+    // XCD owns a contiguous run of pixel tiles and walks (cout tile fastest, then pixel tile): the cout tiles of one pixel
+    // tile -- which read the same patch -- and neighbouring pixel tiles -- which share halo rows -- hit the same L2.
+    int ct, pt;
+    if (a.tiles_per_xcd > 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        ct = j % a.n_ct;
+        pt = xcd * a.tiles_per_xcd + j / a.n_ct;
+        if (j / a.n_ct >= a.tiles_per_xcd || pt >= a.tiles_x * a.tiles_y * a.N) return;  // padding blocks (whole workgroup)
+    } else {                                   // ST3D_WINO_MAP=rr (A/B runs): cout tile fastest, pixel tiles dealt round-robin
+        ct = blockIdx.x % a.n_ct;
+        pt = blockIdx.x / a.n_ct;
+    }
+    const int tile_x = pt % a.tiles_x; pt /= a.tiles_x;
+    const int tile_y = pt % a.tiles_y;
+    const int n = pt / a.tiles_y;
+    int x0 = tile_x * T4_COLS, y0 = tile_y * T4_ROWS;
+    const int co0 = ct * BCO;
+    if (DBG == 2) { x0 = 32; y0 = 8; }       // diagnostic: every workgroup reads the same (cache-resident) patch
+    const int H = a.H, W = a.W;
+    const size_t HW = (size_t)H * W;
+    const int Hp = H >> 1, Wp = W >> 1;
+    const size_t in_plane = (MODE == 2) ? (size_t)Hp * Wp : HW;
+    const int nstages = a.Cin / KS;
+
+    // staging: 8 channels x 6 rows x 10 sixteen-byte items = 480 items per stage, two per thread
+    constexpr int ITEMS = KS * PR4 * 10, IPT = 2;
+    const unsigned kOob = 0x80000000u;
+    unsigned voff[IPT];
+    int loff[IPT];
+    unsigned rowbit[MODE == 2 ? IPT : 1];
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) {
+        const int e = tid + i * NT4;
+        const int ci = e / (PR4 * 10), rem = e - ci * (PR4 * 10);
+        const int r = rem / 10, l = rem - r * 10;
+        const int gy = y0 + r - 1, gx0 = x0 - 4 + 4 * l;
+        const bool ok = e < ITEMS && gy >= 0 && gy < H && gx0 >= 0 && gx0 < W;
+        if (MODE == 2) {
+            voff[i] = ok ? (unsigned)((ci * in_plane + (size_t)(gy >> 1) * Wp + (gx0 >> 1)) * 4) : kOob;
+            rowbit[i] = (gy & 1) << 1;
+        } else {
+            voff[i] = ok ? (unsigned)((ci * in_plane + (size_t)gy * W + gx0) * 4) : kOob;
+        }
+        loff[i] = (e < ITEMS) ? (4 + ci * PS4 + r * PCP + 4 * l - 3) : -1;
+    }
+    const unsigned img_bytes = (unsigned)((size_t)a.Cin * in_plane * 4);
+    const unsigned stage_bytes = (unsigned)(KS * in_plane * 4);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.x + (size_t)n * a.Cin * in_plane), 0, img_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t raux = rx, ridx = rx;
+    if (MODE != 0)
+        raux = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.aux + (size_t)n * a.Cin * in_plane), 0, img_bytes, 0x00020000);
+    if (MODE == 2)
+        ridx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.idx + (size_t)n * a.Cin * in_plane), 0, img_bytes / 4, 0x00020000);
+    const int nsub = a.Cin / KC;
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.U + (size_t)ct * nsub * 4096), 0, (unsigned)((size_t)nsub * 4096 * 4), 0x00020000);
+    const unsigned uvoff0 = (unsigned)((wa * 64 + lane) * 32), uvoff1 = (unsigned)(((wa + 4) * 64 + lane) * 32);
+
+    f32x4 xv[IPT];
+    f32x4 xa[MODE == 1 ? IPT : 1];
+    f32x2 xg[MODE == 2 ? IPT : 1], xp[MODE == 2 ? IPT : 1];
+    unsigned xi[MODE == 2 ? IPT : 1];
+
+    auto gload = [&](int st) __attribute__((always_inline)) {
+        const unsigned so = (unsigned)st * stage_bytes;
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) {
+            if (MODE == 2) {
+                xg[i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rx, voff[i], so, 0));
+                xp[i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(raux, voff[i], so, 0));
+                xi[i] = __builtin_amdgcn_raw_buffer_load_b16(ridx, voff[i] == kOob ? kOob : voff[i] / 4, so / 4, 0);
+            } else {
+                xv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff[i], so, 0));
+                if (MODE == 1) xa[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(raux, voff[i], so, 0));
+            }
+        }
+    };
+    auto lstore = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) {
+            if (loff[i] >= 0) {
+                float *dst = &sP[buf * P4_STAGE + loff[i]];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    float v;
+                    if (MODE == 0) v = xv[i][jj];
+                    if (MODE == 1) v = (xa[i][jj] > 0.f) ? xv[i][jj] : 0.f;
+                    if (MODE == 2) {
+                        const unsigned ib = (xi[i] >> (8 * (jj >> 1))) & 0xffu;
+                        v = (xp[i][jj >> 1] > 0.f && ib == (rowbit[i] | (jj & 1))) ? xg[i][jj >> 1] : 0.f;
+                    }
+                    dst[jj] = v;
+                }
+            }
+        }
+    };
+
+    // B operands: row transform of the wave's row a (t = d[r1] + sg * d[r2]), then the column transform per b
+    const int r1 = (wa == 0) ? 0 : (wa == 2 ? 2 : 1);
+    const int r2 = (wa == 3) ? 3 : (wa == 2 ? 1 : 2);
+    const float sg = (wa == 1) ? 1.f : -1.f;
+    const int lane_off = lhi * PS4 + (2 * (l31 >> 4)) * PCP + 2 * (l31 & 15);
+    const int off1 = lane_off + r1 * PCP, off2 = lane_off + r2 * PCP;
+    struct Raw { f32x2 v[2][2][2]; };          // [ks][row 1/2][column pair]
+    auto pread = [&](int buf, int sub, Raw &d) __attribute__((always_inline)) {
+        const float *p = &sP[buf * P4_STAGE + 4 + sub * KC * PS4];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const float *q1 = p + off1 + (2 * ks) * PS4;
+            const float *q2 = p + off2 + (2 * ks) * PS4;
+            d.v[ks][0][0] = *reinterpret_cast<const f32x2 *>(q1);
+            d.v[ks][0][1] = *reinterpret_cast<const f32x2 *>(q1 + 2);
+            d.v[ks][1][0] = *reinterpret_cast<const f32x2 *>(q2);
+            d.v[ks][1][1] = *reinterpret_cast<const f32x2 *>(q2 + 2);
+        }
+    };
+    struct Bop { float v[2][4]; };             // [ks][q = b]
+    auto bcompute = [&](const Raw &d, Bop &bv) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const float t0 = d.v[ks][0][0][0] + sg * d.v[ks][1][0][0];
+            const float t1 = d.v[ks][0][0][1] + sg * d.v[ks][1][0][1];
+            const float t2 = d.v[ks][0][1][0] + sg * d.v[ks][1][1][0];
+            const float t3 = d.v[ks][0][1][1] + sg * d.v[ks][1][1][1];
+            bv.v[ks][0] = t0 - t2;
+            bv.v[ks][1] = t1 + t2;
+            bv.v[ks][2] = t2 - t1;
+            bv.v[ks][3] = t1 - t3;
+        }
+    };
+
+    f32x16 acc[2][4];      // [cout half][b]
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mh][q][r] = 0.f;
+
+    struct Uop { f32x4 h[2][2]; };             // [cout half][ks] -> 4 floats (q)
+    auto uload = [&](int sub, Uop &u) __attribute__((always_inline)) {
+        const unsigned so = (unsigned)min(sub, nsub - 1) * 16384u;
+        u.h[0][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, uvoff0, so, 0));
+        u.h[0][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, uvoff0 + 16, so, 0));
+        u.h[1][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, uvoff1, so, 0));
+        u.h[1][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, uvoff1 + 16, so, 0));
+    };
+
+    gload(0);
+    lstore(0);
+    gload(nstages > 1 ? 1 : 0);
+    lstore(1);
+    Uop ua, ub;
+    uload(0, ua);
+    __syncthreads();
+    Raw draw;
+    Bop bcur, bnext;
+    pread(0, 0, draw);
+    bcompute(draw, bcur);
+
+#define W4_MFMA(u, bv, ks)                                                                                      \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                             \
+        acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.h[0][ks][q], bv.v[ks][q], acc[0][q], 0, 0, 0);        \
+        acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.h[1][ks][q], bv.v[ks][q], acc[1][q], 0, 0, 0);        \
+    }
+    // one stage = 8 input channels = sub-chunks s0 (operands ready in ua / bcur) and s1; four bursts of 8 MFMAs with the
+    // wave's memory / LDS / VALU work between them (the co-resident workgroup's wave fills the pipe meanwhile)
+    int pb = 0;
+    for (int c = 0; c < nstages; ++c) {
+        const int pb1 = (pb == 2) ? 0 : pb + 1, pb2 = (pb1 == 2) ? 0 : pb1 + 1;
+        W4_MFMA(ua, bcur, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        gload(min(c + 2, nstages - 1));
+        uload(2 * c + 1, ub);
+        pread(pb, 1, draw);
+        __builtin_amdgcn_sched_barrier(0);
+        W4_MFMA(ua, bcur, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        bcompute(draw, bnext);
+        __builtin_amdgcn_sched_barrier(0);
+        W4_MFMA(ub, bnext, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        uload(2 * c + 2, ua);
+        pread(pb1, 0, draw);           // first sub-chunk of the NEXT stage (staged one barrier ago)
+        __builtin_amdgcn_sched_barrier(0);
+        W4_MFMA(ub, bnext, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        bcompute(draw, bcur);
+        lstore(pb2);
+        __syncthreads();
+        pb = pb1;
+    }
+#undef W4_MFMA
+
+    if (DBG == 1) {                          // diagnostic: no epilogue (keeps the accumulators live with one store)
+        float t = 0.f;
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t += acc[mh][q][0];
+        if (t == 12345.678f && a.y) a.y[0] = t;
+        return;
+    }
+    // ---- epilogue: Y = A^T M A.  Along b in registers (z_0 = m0 + m1 + m2, z_1 = m1 - m2 - m3 of this wave's row a),
+    // along a through ONE LDS exchange [2 j][4 a][64 co][32 tiles] (64 KB: both output columns at once, one barrier).
+    // Readers own TWO horizontally adjacent 2x2 tiles of one cout = 4 consecutive pixels on two rows, so the exchange is
+    // read with ds_read_b64 and the image written with 16-byte stores (8 store instructions per lane instead of 16
+    // dwordx2: the tail of a tile is store-issue bound).
+    float *ex = smem;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float z = jj == 0 ? (acc[mh][0][r] + acc[mh][1][r] + acc[mh][2][r])
+                                        : (acc[mh][1][r] - acc[mh][2][r] - acc[mh][3][r]);
+                const int co = mh * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                ex[((jj * 4 + wa) * 64 + co) * 32 + l31] = z;
+            }
+    __syncthreads();
+    const int pair = tid & 15;                        // tiles 2 * pair, 2 * pair + 1 (same tile row)
+    const int oy = y0 + 2 * (pair >> 3), ox = x0 + 4 * (pair & 7);
+    const bool inb = oy < H && ox < W;                // H even, W % 4 == 0: the 2 x 4 pixel item is inside or outside
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int col = it * 16 + (tid >> 4);         // cout within the workgroup's 64
+        const int co = co0 + col;
+        f32x2 z[2][4];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int aa = 0; aa < 4; ++aa)
+                z[jj][aa] = *reinterpret_cast<const f32x2 *>(&ex[((jj * 4 + aa) * 64 + col) * 32 + 2 * pair]);
+        const float bsum = (a.bias && DBG != 4) ? a.bias[co] : 0.f;
+        // y[i][jj] per tile t: i = 0: z0 + z1 + z2, i = 1: z1 - z2 - z3 (along a)
+        float y[2][2][2];      // [tile][row i][col jj]
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                float v0 = z[jj][0][t] + z[jj][1][t] + z[jj][2][t] + bsum;
+                float v1 = z[jj][1][t] - z[jj][2][t] - z[jj][3][t] + bsum;
+                if (a.relu) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
+                y[t][0][jj] = v0; y[t][1][jj] = v1;
+            }
+        if (!inb) continue;
+        if (DBG == 3 && y[0][0][0] != 12345.678f) continue;       // diagnostic: whole epilogue but no global stores
+        if (a.y) {
+            float *dst = a.y + ((size_t)n * a.Cout + co) * HW + (size_t)oy * W + ox;
+            f32x4 q0, q1;
+            q0[0] = y[0][0][0]; q0[1] = y[0][0][1]; q0[2] = y[1][0][0]; q0[3] = y[1][0][1];
+            q1[0] = y[0][1][0]; q1[1] = y[0][1][1]; q1[2] = y[1][1][0]; q1[3] = y[1][1][1];
+            *reinterpret_cast<f32x4 *>(dst) = q0;
+            *reinterpret_cast<f32x4 *>(dst + W) = q1;
+        }
+        if (EPI == 1) {     // MaxPool2d(2,2): first maximum in row-major window order (ATen); two adjacent windows per lane
+            f32x2 best; unsigned short bidx = 0;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float bv = y[t][0][0]; int bi = 0;
+                if (y[t][0][1] > bv || y[t][0][1] != y[t][0][1]) { bv = y[t][0][1]; bi = 1; }
+                if (y[t][1][0] > bv || y[t][1][0] != y[t][1][0]) { bv = y[t][1][0]; bi = 2; }
+                if (y[t][1][1] > bv || y[t][1][1] != y[t][1][1]) { bv = y[t][1][1]; bi = 3; }
+                best[t] = bv; bidx |= (unsigned short)(bi << (8 * t));
+            }
+            const size_t po = ((size_t)n * a.Cout + co) * (size_t)Hp * Wp + (size_t)(oy >> 1) * Wp + (ox >> 1);
+            *reinterpret_cast<f32x2 *>(a.yp + po) = best;
+            if (a.yidx) *reinterpret_cast<unsigned short *>(a.yidx + po) = bidx;
+        }
+    }
+}
+
 // w (Cout,Cin,3,3) -> Winograd-domain filters U = G g G^T (fp64, stored fp32), forward and
 // transposed (g'[ky][kx] = w[co][ci][2-ky][2-kx], channel roles swapped), laid out as the
 // MFMA A operands of wino_kernel: for GEMM (M = out channel m, K = in channel k, xi):
@@ -462,8 +764,47 @@ __global__ void wino_pack_kernel(const float *__restrict__ w, int Cout, int Cin,
     }
 }
 
+// ST3D_WINO_VARIANT=8 / 4 forces one kernel (A/B runs, tools/wino_layers.py).  Default: the half-size workgroups for every
+// layer -- measured faster on all twelve VGG shapes in both directions (4-8 % per layer).
+int wino_variant(const WinoArgs &a) {
+    static const int forced = [] { const char *e = getenv("ST3D_WINO_VARIANT"); return e ? atoi(e) : 0; }();
+    if (forced == 4 || forced == 8) return forced;
+    return 4;
+}
+
+template <int MODE>
+int launch_wino4(WinoArgs a, hipStream_t s) {
+    a.tiles_x = st3d::cdiv(a.W, T4_COLS);
+    a.tiles_y = st3d::cdiv(a.H, T4_ROWS);
+    a.n_ct = a.Cout / BCO;
+    const long ntiles = (long)a.tiles_x * a.tiles_y * a.N;
+    // block -> (pixel tile, cout tile): XCD-chunked for the full-resolution inputs (measured 1-6 % faster than dealing pixel
+    // tiles round-robin: halo rows and the cout tiles' shared patch hit the XCD's L2), round-robin for the fused-unpool
+    // input-gradient, whose pooled-resolution operands are a quarter of the size (measured 2-4 % faster there).
+    // ST3D_WINO_MAP=rr / xcd forces one mapping (A/B runs).
+    static const int forced = [] { const char *e = getenv("ST3D_WINO_MAP"); return !e ? 0 : (strcmp(e, "rr") == 0 ? 1 : 2); }();
+    const bool rr = forced ? forced == 1 : MODE == 2;
+    a.tiles_per_xcd = rr ? 0 : (int)((ntiles + 7) / 8);
+    const long blocks = rr ? ntiles * a.n_ct : 8L * a.tiles_per_xcd * a.n_ct;   // bid & 7 = XCD, bid >> 3 = (pixel tile in the XCD's run, cout tile)
+#ifdef ST3D_WINO_DEBUG
+    static const int dbgmode = [] { const char *e = getenv("ST3D_WINO_DBGMODE"); return e ? atoi(e) : 0; }();
+    if (dbgmode == 1 && MODE == 0) { wino4_kernel<0, 0, 1><<<(unsigned)blocks, NT4, 0, s>>>(a); return ST3D_OK; }
+    if ((dbgmode == 3 || dbgmode == 4) && MODE == 0) {
+        if (dbgmode == 3) { if (a.yp) wino4_kernel<0, 1, 3><<<(unsigned)blocks, NT4, 0, s>>>(a); else wino4_kernel<0, 0, 3><<<(unsigned)blocks, NT4, 0, s>>>(a); }
+        else { if (a.yp) wino4_kernel<0, 1, 4><<<(unsigned)blocks, NT4, 0, s>>>(a); else wino4_kernel<0, 0, 4><<<(unsigned)blocks, NT4, 0, s>>>(a); }
+        return ST3D_OK;
+    }
+    if (dbgmode == 2 && MODE == 0) { if (a.yp) wino4_kernel<0, 1, 2><<<(unsigned)blocks, NT4, 0, s>>>(a); else wino4_kernel<0, 0, 2><<<(unsigned)blocks, NT4, 0, s>>>(a); return ST3D_OK; }
+#endif
+    if (a.yp) wino4_kernel<MODE, 1><<<(unsigned)blocks, NT4, 0, s>>>(a);
+    else wino4_kernel<MODE, 0><<<(unsigned)blocks, NT4, 0, s>>>(a);
+    ST3D_LAUNCH_CHECK();
+    return ST3D_OK;
+}
+
 template <int MODE>
 int launch_wino(WinoArgs a, hipStream_t s) {
+    if (wino_variant(a) == 4 && !a.dbg) return launch_wino4<MODE>(a, s);
     a.tiles_x = st3d::cdiv(a.W, TCOLS);
     a.tiles_y = st3d::cdiv(a.H, TROWS);
     a.n_ct = a.Cout / BCO;
@@ -509,7 +850,7 @@ extern "C" int st3d_wino_fwd(const float *x, const float *u_fwd, const float *bi
 #ifdef ST3D_WINO_DEBUG      // diagnostic builds only (tools/wino_bench.py): device pointer for the s_memtime stamps
     if (const char *e = getenv("ST3D_WINO_STAMP")) dbg = reinterpret_cast<unsigned long long *>(strtoull(e, nullptr, 0));
 #endif
-    WinoArgs a{x, nullptr, nullptr, u_fwd, bias, y, y_pooled, pool_idx, N, Cin, Cout, H, W, relu, 0, 0, 0, dbg};
+    WinoArgs a{x, nullptr, nullptr, u_fwd, bias, y, y_pooled, pool_idx, N, Cin, Cout, H, W, relu, 0, 0, 0, 0, dbg};
     return launch_wino<0>(a, st3d::as_stream(stream));
 }
 
@@ -518,7 +859,7 @@ extern "C" int st3d_wino_dgrad(const float *gy, const float *act, const float *u
     ST3D_CHECK_ARG(gy && u_dgrad && gx);
     ST3D_CHECK_ARG(N > 0 && shape_ok(Cout, Cin, H, W));
     ST3D_CHECK_ARG(((uintptr_t)u_dgrad & 15) == 0);
-    WinoArgs a{gy, act, nullptr, u_dgrad, nullptr, gx, nullptr, nullptr, N, Cout, Cin, H, W, 0, 0, 0, 0, nullptr};
+    WinoArgs a{gy, act, nullptr, u_dgrad, nullptr, gx, nullptr, nullptr, N, Cout, Cin, H, W, 0, 0, 0, 0, 0, nullptr};
     return act ? launch_wino<1>(a, st3d::as_stream(stream)) : launch_wino<0>(a, st3d::as_stream(stream));
 }
 
@@ -528,6 +869,6 @@ extern "C" int st3d_wino_dgrad_unpool(const float *gy_pooled, const uint8_t *poo
     ST3D_CHECK_ARG(gy_pooled && pool_idx && pooled && u_dgrad && gx);
     ST3D_CHECK_ARG(N > 0 && shape_ok(Cout, Cin, H, W));
     ST3D_CHECK_ARG(((uintptr_t)u_dgrad & 15) == 0);
-    WinoArgs a{gy_pooled, pooled, pool_idx, u_dgrad, nullptr, gx, nullptr, nullptr, N, Cout, Cin, H, W, 0, 0, 0, 0, nullptr};
+    WinoArgs a{gy_pooled, pooled, pool_idx, u_dgrad, nullptr, gx, nullptr, nullptr, N, Cout, Cin, H, W, 0, 0, 0, 0, 0, nullptr};
     return launch_wino<2>(a, st3d::as_stream(stream));
 }
