@@ -17,7 +17,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int KCH = 32;
+constexpr int KCH0 = 32;          // K chunk of the general kernels; the short-K backward of C = 64 / 128 stages 64 at once
 
 struct GemmArgs {
     const float *A; const float *B; float *C;
@@ -44,7 +44,7 @@ __device__ __forceinline__ float4 load4(const float *p, int remain, bool aligned
 // MT/NT: 32x32 MFMA tiles per wave along M/N.  BMODE 0: B is [N][K]; 1: B is [K][N].
 // DIAG 1: the only tile of a Gram forward whose C fits one tile (C = 64, 128) -- the B tile IS the A tile, fetched and
 // staged once (compile-time: the run-time test cost the multi-tile layers more than it saved them).
-template <int MT, int NT, int BMODE, int DIAG = 0>
+template <int MT, int NT, int BMODE, int DIAG = 0, int KCH = 32>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     constexpr int TM = 2 * MT * 32, TN = 2 * NT * 32;
     constexpr int LA = TM + 1;
@@ -77,19 +77,31 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     const bool a_al = ((g.lda & 3) == 0) && ((((uintptr_t)Ab) & 15) == 0);
     const bool b_al = ((g.ldb & 3) == 0) && ((((uintptr_t)Bb) & 15) == 0);
 
+    // C = coef * A B (+ C): the accumulators START from the destination tile when accumulating (its loads are in flight
+    // under the first operand tiles instead of a dependent load -> add -> store chain behind the last MFMA) and coef is
+    // folded into the A tile on its way into LDS, so the epilogue is a plain store.
+    float *Cb = g.C + b * g.sC + split * g.sSplit;
     f32x16 acc[MT][NT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int q = 0; q < NT; ++q)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                float v = 0.f;
+                if (g.accumulate) {
+                    const int gm = m0 + wm * (MT * 32) + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    const int gn = n0 + wn * (NT * 32) + q * 32 + l31;
+                    if (gm < g.M && gn < g.N) v = Cb[(size_t)gm * g.ldc + gn];
+                }
+                acc[m][q][r] = v;
+            }
 
     float4 av[A4], bv[B4];
     auto load_tiles = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < A4; ++i) {       // A tile: TM rows x 32 k, 8 float4 per row
-            const int e = tid + i * 256, row = e >> 3, kq = (e & 7) * 4;
+            const int e = tid + i * 256, row = e / (KCH / 4), kq = (e % (KCH / 4)) * 4;
             const int gm = m0 + row, gk = k0 + kq;
             av[i] = (gm < g.M) ? load4(Ab + (size_t)gm * g.lda + gk, kend - gk, a_al && ((gk & 3) == 0))
                                : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -99,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         for (int i = 0; i < B4; ++i) {
             const int e = tid + i * 256;
             if (BMODE == 0) {                // [N][K]: TN rows x 32 k
-                const int row = e >> 3, kq = (e & 7) * 4;
+                const int row = e / (KCH / 4), kq = (e % (KCH / 4)) * 4;
                 const int gn = n0 + row, gk = k0 + kq;
                 bv[i] = (gn < g.N) ? load4(Bb + (size_t)gn * g.ldb + gk, kend - gk, b_al && ((gk & 3) == 0))
                                    : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -114,16 +126,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     auto store_tiles = [&]() {
 #pragma unroll
         for (int i = 0; i < A4; ++i) {
-            const int e = tid + i * 256, row = e >> 3, kq = (e & 7) * 4;
-            As[(kq + 0) * LA + row] = av[i].x; As[(kq + 1) * LA + row] = av[i].y;
-            As[(kq + 2) * LA + row] = av[i].z; As[(kq + 3) * LA + row] = av[i].w;
+            const int e = tid + i * 256, row = e / (KCH / 4), kq = (e % (KCH / 4)) * 4;
+            As[(kq + 0) * LA + row] = g.coef * av[i].x; As[(kq + 1) * LA + row] = g.coef * av[i].y;
+            As[(kq + 2) * LA + row] = g.coef * av[i].z; As[(kq + 3) * LA + row] = g.coef * av[i].w;
         }
         if (diag) return;
 #pragma unroll
         for (int i = 0; i < B4; ++i) {
             const int e = tid + i * 256;
             if (BMODE == 0) {
-                const int row = e >> 3, kq = (e & 7) * 4;
+                const int row = e / (KCH / 4), kq = (e % (KCH / 4)) * 4;
                 Bs[(kq + 0) * LB + row] = bv[i].x; Bs[(kq + 1) * LB + row] = bv[i].y;
                 Bs[(kq + 2) * LB + row] = bv[i].z; Bs[(kq + 3) * LB + row] = bv[i].w;
             } else {
@@ -156,7 +168,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         }
     }
 
-    float *Cb = g.C + b * g.sC + split * g.sSplit;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -167,9 +178,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
             for (int q = 0; q < NT; ++q) {
                 const int gn = n0 + wn * (NT * 32) + q * 32 + l31;
                 if (gn < g.N) {
-                    float *dst = Cb + (size_t)gm * g.ldc + gn;
-                    const float v = g.coef * acc[m][q][r];
-                    *dst = g.accumulate ? (*dst + v) : v;
+                    Cb[(size_t)gm * g.ldc + gn] = acc[m][q][r];
                 }
             }
         }
@@ -222,12 +231,12 @@ int gram_split(int B, int C, int HW, int *kper) {
     }
     const int ns_bytes = (HW + 2047) / 2048;            // never more than 2048 pixels per workgroup
     if (ns < ns_bytes) ns = ns_bytes;
-    const int ns_max = (HW + 8 * KCH - 1) / (8 * KCH);   // at least 8 K-chunks (256 pixels) of work per workgroup (4 measured slower)
+    const int ns_max = (HW + 8 * KCH0 - 1) / (8 * KCH0);   // at least 8 K-chunks (256 pixels) of work per workgroup (4 measured slower)
     if (ns > ns_max) ns = ns_max;
     if (ns > 256) ns = 256;
     if (ns < 1) ns = 1;
     int kp = (HW + ns - 1) / ns;
-    kp = (kp + KCH - 1) / KCH * KCH;
+    kp = (kp + KCH0 - 1) / KCH0 * KCH0;
     ns = (HW + kp - 1) / kp;
     *kper = kp;
     return ns;
@@ -278,7 +287,7 @@ extern "C" int st3d_gram_bwd(const float *D, const float *feat, int B, int C, in
     g.A = D; g.B = feat; g.C = gfeat;
     g.M = C; g.N = HW; g.K = C; g.lda = C; g.ldb = HW; g.ldc = HW;
     g.sA = (size_t)C * C; g.sB = g.sC = (size_t)C * HW;
-    g.nsplit = 1; g.kper = (C + KCH - 1) / KCH * KCH; g.sSplit = 0;
+    g.nsplit = 1; g.kper = (C + 63) / 64 * 64; g.sSplit = 0;
     g.tri = 0; g.coef = coef; g.accumulate = accumulate;
     hipStream_t s = st3d::as_stream(stream);
     // 128-row tiles only where they leave enough workgroups (>= 1024) and D is wide (measured, tools/gram_bwd_sweep.py:
@@ -287,7 +296,27 @@ extern "C" int st3d_gram_bwd(const float *D, const float *feat, int B, int C, in
     bool tall = C % 128 == 0 && C >= 256 && (long)(C / 128) * st3d::cdiv(HW, 128) * B >= 1024;
     if (force && force[0] == '1') tall = false;
     if (force && force[0] == '2' && C % 128 == 0) tall = true;
-    if (tall) {
+    // C = 128 at large HW: 128 rows x 64 pixels per workgroup -- F is streamed once (64-row tiles read it twice) while the
+    // grid keeps as many workgroups as the 64 x 128 tiling
+    bool wide = C == 128 && !tall;
+    if (force) wide = force[0] == '3' && C % 128 == 0;
+    static const bool k64 = [] { const char *e = getenv("ST3D_GRAM_BWD_K64"); return e && e[0] == '1'; }();
+    if (force && force[0] == '4') {             // 64 rows x 256 pixels (1 KB row segments)
+        g.tiles_m = st3d::cdiv(C, 64); g.tiles_n = st3d::cdiv(HW, 256);
+        gemm_kernel<1, 4, 1><<<dim3(g.tiles_m * g.tiles_n, 1, B), 256, 0, s>>>(g);
+        ST3D_LAUNCH_CHECK();
+        return ST3D_OK;
+    }
+    if (wide) {
+        g.tiles_m = C / 128; g.tiles_n = st3d::cdiv(HW, 64);
+        if (k64) gemm_kernel<2, 1, 1, 0, 64><<<dim3(g.tiles_m * g.tiles_n, 1, B), 256, 0, s>>>(g);
+        else gemm_kernel<2, 1, 1><<<dim3(g.tiles_m * g.tiles_n, 1, B), 256, 0, s>>>(g);
+    } else if (C <= 128 && !tall && k64) {
+        // short K (= C): the whole reduction (C = 64) or half of it is staged at once, so a workgroup has its operand tile and
+        // the accumulate tile in flight together instead of one 32-row chunk after the other
+        g.tiles_m = st3d::cdiv(C, 64); g.tiles_n = st3d::cdiv(HW, 128);
+        gemm_kernel<1, 2, 1, 0, 64><<<dim3(g.tiles_m * g.tiles_n, 1, B), 256, 0, s>>>(g);
+    } else if (tall) {
         g.tiles_m = C / 128; g.tiles_n = st3d::cdiv(HW, 128);
         gemm_kernel<2, 2, 1><<<dim3(g.tiles_m * g.tiles_n, 1, B), 256, 0, s>>>(g);
     } else {

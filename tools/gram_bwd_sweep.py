@@ -21,9 +21,20 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
             ops.gram_bwd(D, f, 0.5, out=acc)
         e1.record(); torch.cuda.synchronize()
         out[f"{C}x{H}"] = round(e0.elapsed_time(e1) / 20 * 1e3, 1)
+        if os.environ.get("SWEEP_EXTRA"):
+            e0.record()
+            for _ in range(20):
+                ops.gram_bwd(D, f, 0.5)          # no accumulate (allocates the output: includes torch.empty)
+            e1.record(); torch.cuda.synchronize()
+            out[f"{C}x{H}_store"] = round(e0.elapsed_time(e1) / 20 * 1e3, 1)
+            e0.record()
+            for _ in range(20):
+                acc.add_(f)
+            e1.record(); torch.cuda.synchronize()
+            out[f"{C}x{H}_axpy"] = round(e0.elapsed_time(e1) / 20 * 1e3, 1)
     print(json.dumps(out))
     sys.exit(0)
-for mt in ("", "1"):
+for mt in ("", "1", "2", "3", "4"):
     env = dict(os.environ)
     if mt:
         env["ST3D_GRAM_BWD_MT"] = mt
