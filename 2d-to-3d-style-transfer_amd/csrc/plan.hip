@@ -234,6 +234,57 @@ int forward(st3d_plan *p, const float *imgs, int n, int upto, bool keep_full, hi
     return ST3D_OK;
 }
 
+// g = (accumulate ? g : 0) + x
+__global__ __launch_bounds__(256) void add_kernel(const float *__restrict__ x, size_t n, int accumulate, float *__restrict__ g) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) g[i] = accumulate ? g[i] + x[i] : x[i];
+}
+
+// backward of MaxPool2d(2,2) as a stand-alone pass: out (planes,H,W) = scatter of gp (planes,H/2,W/2) to the argmax
+// positions (+ `add`, a full-resolution gradient arriving at the same tensor, when given).  Only the differentiable
+// get_features needs it (a tap on a conv that feeds a pool); the loss plan fuses the unpool into the dgrad kernel.
+__global__ __launch_bounds__(256) void unpool_add_kernel(const float *__restrict__ gp, const uint8_t *__restrict__ idx,
+                                                         const float *__restrict__ add, size_t planes, int H, int W,
+                                                         float *__restrict__ out) {
+    const int Hp = H / 2, Wp = W / 2;
+    const size_t n = planes * (size_t)Hp * Wp;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int xo = (int)(i % Wp), yo = (int)((i / Wp) % Hp);
+    const size_t pl = i / ((size_t)Wp * Hp);
+    const float g = gp ? gp[i] : 0.f;
+    const int k = gp ? idx[i] : -1;
+    const size_t base = pl * H * W + (size_t)(2 * yo) * W + 2 * xo;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const size_t o = base + (size_t)(q >> 1) * W + (q & 1);
+        out[o] = (q == k ? g : 0.f) + (add ? add[o] : 0.f);
+    }
+}
+
+// one input-gradient launch of conv slot cs: g (gradient w.r.t. the conv's post-ReLU output, or w.r.t. the output of
+// the pool behind it when pooled) -> dst (gradient w.r.t. the conv's input)
+int dgrad_step(st3d_plan *p, int cs, const float *g, bool g_is_pooled, int pool_of_g, float *dst, int n, hipStream_t s) {
+    const int m = kConvIdx[cs];
+    const int H = p->H[m], W = p->W[m];
+    const bool wino = p->vgg->use_wino && p->vgg->ud[cs] && st3d_wino_supported(kConvCout[cs], kConvCin[cs], H, W);
+    Scope sc(p, wino ? F_CONV_DGRAD : F_CONVX_DGRAD, s, m);
+    if (g_is_pooled) {
+        if (wino)
+            ST3D_TRY(st3d_wino_dgrad_unpool(g, p->pidx[pool_of_g], p->act[kPoolIdx[pool_of_g]], p->vgg->ud[cs], dst, n,
+                                            kConvCin[cs], kConvCout[cs], H, W, s));
+        else
+            ST3D_TRY(st3d_conv3x3_dgrad_unpool(g, p->pidx[pool_of_g], p->act[kPoolIdx[pool_of_g]], p->vgg->wd[cs], dst, n,
+                                               kConvCin[cs], kConvCout[cs], H, W, s));
+    } else {
+        if (wino)
+            ST3D_TRY(st3d_wino_dgrad(g, p->act[m], p->vgg->ud[cs], dst, n, kConvCin[cs], kConvCout[cs], H, W, s));
+        else
+            ST3D_TRY(st3d_conv3x3_dgrad(g, p->act[m], p->vgg->wd[cs], dst, n, kConvCin[cs], kConvCout[cs], H, W, s));
+    }
+    return ST3D_OK;
+}
+
 }  // namespace
 
 extern "C" int st3d_plan_create(st3d_plan **out, st3d_vgg *vgg, int B, int S) {
@@ -435,29 +486,80 @@ extern "C" int st3d_plan_loss(st3d_plan *p, const float *current, int n, int bat
         }
         if (!have_g) continue;
         float *dst = (cs == 0) ? grad_current : gn;
-        {
-            const bool wino = p->vgg->use_wino && p->vgg->ud[cs] && st3d_wino_supported(kConvCout[cs], kConvCin[cs], H, W);
-            Scope sc(p, wino ? F_CONV_DGRAD : F_CONVX_DGRAD, s, m);
-            if (g_is_pooled) {
-                if (wino)
-                    ST3D_TRY(st3d_wino_dgrad_unpool(g, p->pidx[pool_of_g], p->act[kPoolIdx[pool_of_g]], p->vgg->ud[cs], dst, n,
-                                                    kConvCin[cs], kConvCout[cs], H, W, s));
-                else
-                    ST3D_TRY(st3d_conv3x3_dgrad_unpool(g, p->pidx[pool_of_g], p->act[kPoolIdx[pool_of_g]], p->vgg->wd[cs], dst,
-                                                       n, kConvCin[cs], kConvCout[cs], H, W, s));
-            } else {
-                if (wino)
-                    ST3D_TRY(st3d_wino_dgrad(g, p->act[m], p->vgg->ud[cs], dst, n, kConvCin[cs], kConvCout[cs], H, W, s));
-                else
-                    ST3D_TRY(st3d_conv3x3_dgrad(g, p->act[m], p->vgg->wd[cs], dst, n, kConvCin[cs], kConvCout[cs], H, W, s));
-            }
-        }
+        ST3D_TRY(dgrad_step(p, cs, g, g_is_pooled, pool_of_g, dst, n, s));
         // dst is the gradient w.r.t. this conv's input: either the previous conv's post-ReLU
         // output or a pool output (then the next dgrad fuses the unpool)
         g_is_pooled = (m > 0) && pool_slot(m - 1) >= 0;
         pool_of_g = g_is_pooled ? pool_slot(m - 1) : -1;
         float *t = g; g = gn; gn = t;
     }
+    return ST3D_OK;
+}
+
+// Backward of st3d_plan_forward for external losses on the taps (differentiable get_features, style_transfer.py:61-83):
+// grad_modules[m] (host array of kModules device pointers, NULL = no gradient) is d loss / d (output of VGG module m) for
+// the n images of the LAST forward, whose activations (post-ReLU outputs, pooled values, argmax) are still in the plan.
+// A conv module and the in-place ReLU behind it are the same tensor, so gradients given for either are
+// summed.  -> grad_image (n,3,S,S).
+extern "C" int st3d_plan_backward(st3d_plan *p, int n, int upto_module, const float *const *grad_modules, float *grad_image,
+                                  st3d_stream_t stream) {
+    ST3D_CHECK_ARG(p && grad_modules && grad_image);
+    ST3D_CHECK_ARG(n > 0 && n <= p->B && n == p->last_n && upto_module >= 0 && upto_module < kModules);
+    hipStream_t s = st3d::as_stream(stream);
+    float *g = p->gbuf[0], *gn = p->gbuf[1];
+    bool have_g = false, g_is_pooled = false;
+    int pool_of_g = -1;
+    int top = -1;
+    for (int cs = 0; cs < 16; ++cs)
+        if (kConvIdx[cs] <= upto_module) top = cs;
+    for (int m = 0; m < kModules; ++m)
+        if (grad_modules[m] && m > upto_module) {
+            st3d::set_error("st3d_plan_backward: gradient given for module %d beyond the forward's last module %d", m, upto_module);
+            return ST3D_E_INVALID;
+        }
+    auto blocks = [](size_t cnt) { const size_t b = (cnt + 255) / 256; return (unsigned)(b > 65535 * 16 ? 65535 * 16 : b); };
+    for (int cs = top; cs >= 0; --cs) {
+        const int m = kConvIdx[cs];
+        const int C = p->C[m], H = p->H[m], W = p->W[m];
+        const size_t full = (size_t)n * C * H * W;
+        const int ps = (m + 2 < kModules && m + 2 <= upto_module) ? pool_slot(m + 2) : -1;
+        // (1) a gradient on the pool behind this conv joins the pooled-resolution gradient from above
+        if (ps >= 0 && grad_modules[m + 2]) {
+            Scope sc(p, F_ELEM, s);
+            const size_t pooled = (size_t)n * C * p->H[m + 2] * p->W[m + 2];
+            add_kernel<<<blocks(pooled), 256, 0, s>>>(grad_modules[m + 2], pooled, have_g ? 1 : 0, g);
+            ST3D_LAUNCH_CHECK();
+            have_g = true; g_is_pooled = true; pool_of_g = ps;
+        }
+        // (2) gradients on the conv's own (post-ReLU) output
+        for (int k = 0; k < 2; ++k) {
+            const float *tap = (m + k <= upto_module) ? grad_modules[m + k] : nullptr;
+            if (!tap) continue;
+            Scope sc(p, F_ELEM, s);
+            if (have_g && g_is_pooled) {        // bring the pooled gradient to full resolution first, adding the tap on the way
+                const size_t pooled = (size_t)n * C * (H / 2) * (W / 2);
+                const bool odd = (H & 1) || (W & 1);          // MaxPool2d floors: the last row / column has no window
+                if (odd) ST3D_HIP(hipMemsetAsync(gn, 0, full * sizeof(float), s));
+                unpool_add_kernel<<<(unsigned)((pooled + 255) / 256), 256, 0, s>>>(g, p->pidx[pool_of_g], odd ? nullptr : tap,
+                                                                                (size_t)n * C, H, W, gn);
+                ST3D_LAUNCH_CHECK();
+                if (odd) { add_kernel<<<blocks(full), 256, 0, s>>>(tap, full, 1, gn); ST3D_LAUNCH_CHECK(); }
+                float *t = g; g = gn; gn = t;
+                g_is_pooled = false; pool_of_g = -1;
+            } else {
+                add_kernel<<<blocks(full), 256, 0, s>>>(tap, full, have_g ? 1 : 0, g);
+                ST3D_LAUNCH_CHECK();
+            }
+            have_g = true;
+        }
+        if (!have_g) continue;
+        float *dst = (cs == 0) ? grad_image : gn;
+        ST3D_TRY(dgrad_step(p, cs, g, g_is_pooled, pool_of_g, dst, n, s));
+        g_is_pooled = (m > 0) && pool_slot(m - 1) >= 0;
+        pool_of_g = g_is_pooled ? pool_slot(m - 1) : -1;
+        float *t = g; g = gn; gn = t;
+    }
+    if (!have_g) ST3D_HIP(hipMemsetAsync(grad_image, 0, (size_t)n * 3 * p->S * p->S * sizeof(float), s));
     return ST3D_OK;
 }
 

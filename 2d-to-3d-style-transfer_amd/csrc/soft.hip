@@ -40,7 +40,7 @@ __device__ __forceinline__ float pld2(float px, float py, float ax, float ay, fl
 // face records as in raster.hip: [x0 y0 z0 x1][y1 z1 x2 y2][z2 valid 0 0]
 template <int K>
 __global__ __launch_bounds__(256) void raster_k_kernel(const float4 *__restrict__ rec, int F, int S, float blur, int clip,
-                                                       int32_t *__restrict__ pix_to_face, float *__restrict__ zbuf,
+                                                       int cull, int persp, int32_t *__restrict__ pix_to_face, float *__restrict__ zbuf,
                                                        float *__restrict__ bary, float *__restrict__ dists) {
     __shared__ float s_face[LIST_CAP][9];
     __shared__ int s_fidx[LIST_CAP];
@@ -95,13 +95,18 @@ __global__ __launch_bounds__(256) void raster_k_kernel(const float4 *__restrict_
                 const float xmin = fminf(x0, fminf(x1, x2)) - pad, xmax = fmaxf(x0, fmaxf(x1, x2)) + pad;
                 const float ymin = fminf(y0, fminf(y1, y2)) - pad, ymax = fmaxf(y0, fmaxf(y1, y2)) + pad;
                 if (xf > xmax || xf < xmin || yf > ymax || yf < ymin) continue;
-                const float area = edge_fn(x2, y2, x0, y0, x1, y1) + kEps;
+                const float face_area = edge_fn(x2, y2, x0, y0, x1, y1);
+                if (cull && face_area < 0.f) continue;      // cull_backfaces: the face winds away from the camera
+                const float area = face_area + kEps;
                 const float w0 = edge_fn(xf, yf, x1, y1, x2, y2) / area;
                 const float w1 = edge_fn(xf, yf, x2, y2, x0, y0) / area;
                 const float w2 = edge_fn(xf, yf, x0, y0, x1, y1) / area;
-                const float t0 = w0 * z1 * z2, t1 = z0 * w1 * z2, t2 = z0 * z1 * w2;
-                const float den = fmaxf(t0 + t1 + t2, kEps);
-                const float b0 = t0 / den, b1 = t1 / den, b2 = t2 / den;
+                float b0 = w0, b1 = w1, b2 = w2;            // perspective_correct = False: screen-space barycentrics
+                if (persp) {
+                    const float t0 = w0 * z1 * z2, t1 = z0 * w1 * z2, t2 = z0 * z1 * w2;
+                    const float den = fmaxf(t0 + t1 + t2, kEps);
+                    b0 = t0 / den; b1 = t1 / den; b2 = t2 / den;
+                }
                 float c0 = b0, c1 = b1, c2 = b2;
                 if (clip) {
                     c0 = fminf(fmaxf(b0, 0.f), 1.f); c1 = fminf(fmaxf(b1, 0.f), 1.f); c2 = fminf(fmaxf(b2, 0.f), 1.f);
@@ -305,7 +310,8 @@ __global__ __launch_bounds__(256) void soft_shade_kernel(const SoftArgs a, float
 __global__ __launch_bounds__(256) void raster_k_bwd_kernel(const float *__restrict__ gbary, const float *__restrict__ gzb,
                                                            const float *__restrict__ gdist, const int32_t *__restrict__ p2f,
                                                            const float *__restrict__ ndc, const int32_t *__restrict__ faces,
-                                                           int B, int V, int S, int K, int clip, float *__restrict__ gndc) {
+                                                           int B, int V, int S, int K, int clip, int persp,
+                                                           float *__restrict__ gndc) {
     const size_t HW = (size_t)S * S;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)B * HW * K) return;
@@ -327,7 +333,8 @@ __global__ __launch_bounds__(256) void raster_k_bwd_kernel(const float *__restri
     const float t0 = w0 * z1 * z2, t1 = z0 * w1 * z2, t2 = z0 * z1 * w2;
     const float den = t0 + t1 + t2;
     float gx0 = 0.f, gy0 = 0.f, gx1 = 0.f, gy1 = 0.f, gx2 = 0.f, gy2 = 0.f, dz0 = 0.f, dz1 = 0.f, dz2 = 0.f;
-    const float b0 = t0 / fmaxf(den, kEps), b1 = t1 / fmaxf(den, kEps), b2 = t2 / fmaxf(den, kEps);
+    const float b0 = persp ? t0 / fmaxf(den, kEps) : w0, b1 = persp ? t1 / fmaxf(den, kEps) : w1,
+                b2 = persp ? t2 / fmaxf(den, kEps) : w2;
     // ---- clipped barycentrics + depth
     float c0 = b0, c1 = b1, c2 = b2, s = 1.f;
     if (clip) {
@@ -349,13 +356,16 @@ __global__ __launch_bounds__(256) void raster_k_bwd_kernel(const float *__restri
         db1 = (b1 > 0.f && b1 < 1.f) ? e1 : 0.f;
         db2 = (b2 > 0.f && b2 < 1.f) ? e2 : 0.f;
     }
-    if (den > kEps) {
-        const float gs = db0 * b0 + db1 * b1 + db2 * b2;
-        const float dt0 = (db0 - gs) / den, dt1 = (db1 - gs) / den, dt2 = (db2 - gs) / den;
-        const float dw0 = dt0 * z1 * z2, dw1 = dt1 * z0 * z2, dw2 = dt2 * z0 * z1;
-        dz0 += dt1 * w1 * z2 + dt2 * z1 * w2;
-        dz1 += dt0 * w0 * z2 + dt2 * z0 * w2;
-        dz2 += dt0 * w0 * z1 + dt1 * z0 * w1;
+    if (!persp || den > kEps) {
+        float dw0 = db0, dw1 = db1, dw2 = db2;          // perspective_correct = False: b = w
+        if (persp) {
+            const float gs = db0 * b0 + db1 * b1 + db2 * b2;
+            const float dt0 = (db0 - gs) / den, dt1 = (db1 - gs) / den, dt2 = (db2 - gs) / den;
+            dw0 = dt0 * z1 * z2; dw1 = dt1 * z0 * z2; dw2 = dt2 * z0 * z1;
+            dz0 += dt1 * w1 * z2 + dt2 * z1 * w2;
+            dz1 += dt0 * w0 * z2 + dt2 * z0 * w2;
+            dz2 += dt0 * w0 * z1 + dt1 * z0 * w1;
+        }
         const float de0 = dw0 / A, de1 = dw1 / A, de2 = dw2 / A;
         const float dA = -(dw0 * w0 + dw1 * w1 + dw2 * w2) / A;
         gx0 += de1 * -(py - y2) + de2 * (py - y1) + dA * (y2 - y1);
@@ -397,30 +407,30 @@ __global__ __launch_bounds__(256) void raster_k_bwd_kernel(const float *__restri
 }
 
 template <int K>
-void launch_raster_k(const float4 *rec, int B, int F, int S, float blur, int clip, int32_t *p2f, float *zbuf, float *bary,
-                     float *dists, hipStream_t s) {
+void launch_raster_k(const float4 *rec, int B, int F, int S, float blur, int clip, int cull, int persp, int32_t *p2f,
+                     float *zbuf, float *bary, float *dists, hipStream_t s) {
     const int tiles = st3d::cdiv(S, TILE);
-    raster_k_kernel<K><<<dim3(tiles, tiles, B), 256, 0, s>>>(rec, F, S, blur, clip, p2f, zbuf, bary, dists);
+    raster_k_kernel<K><<<dim3(tiles, tiles, B), 256, 0, s>>>(rec, F, S, blur, clip, cull, persp, p2f, zbuf, bary, dists);
 }
 
 }  // namespace
 
 extern "C" int st3d_raster_soft_fwd(const float *face_records, int B, int F, int S, int K, float blur_radius, int clip_bary,
-                                    int32_t *pix_to_face, float *zbuf, float *bary, float *dists, st3d_stream_t stream) {
+                                    int cull_backfaces, int perspective_correct, int32_t *pix_to_face, float *zbuf, float *bary, float *dists, st3d_stream_t stream) {
     ST3D_CHECK_ARG(face_records && pix_to_face && zbuf && bary && dists);
     ST3D_CHECK_ARG(B > 0 && F > 0 && S > 0 && K >= 1 && K <= 8 && blur_radius >= 0.f);
     ST3D_CHECK_ARG(((uintptr_t)face_records & 15) == 0);
     hipStream_t s = st3d::as_stream(stream);
     const float4 *rec = reinterpret_cast<const float4 *>(face_records);
     switch (K) {
-        case 1: launch_raster_k<1>(rec, B, F, S, blur_radius, clip_bary, pix_to_face, zbuf, bary, dists, s); break;
-        case 2: launch_raster_k<2>(rec, B, F, S, blur_radius, clip_bary, pix_to_face, zbuf, bary, dists, s); break;
-        case 3: launch_raster_k<3>(rec, B, F, S, blur_radius, clip_bary, pix_to_face, zbuf, bary, dists, s); break;
-        case 4: launch_raster_k<4>(rec, B, F, S, blur_radius, clip_bary, pix_to_face, zbuf, bary, dists, s); break;
-        case 5: launch_raster_k<5>(rec, B, F, S, blur_radius, clip_bary, pix_to_face, zbuf, bary, dists, s); break;
-        case 6: launch_raster_k<6>(rec, B, F, S, blur_radius, clip_bary, pix_to_face, zbuf, bary, dists, s); break;
-        case 7: launch_raster_k<7>(rec, B, F, S, blur_radius, clip_bary, pix_to_face, zbuf, bary, dists, s); break;
-        default: launch_raster_k<8>(rec, B, F, S, blur_radius, clip_bary, pix_to_face, zbuf, bary, dists, s); break;
+        case 1: launch_raster_k<1>(rec, B, F, S, blur_radius, clip_bary, cull_backfaces, perspective_correct, pix_to_face, zbuf, bary, dists, s); break;
+        case 2: launch_raster_k<2>(rec, B, F, S, blur_radius, clip_bary, cull_backfaces, perspective_correct, pix_to_face, zbuf, bary, dists, s); break;
+        case 3: launch_raster_k<3>(rec, B, F, S, blur_radius, clip_bary, cull_backfaces, perspective_correct, pix_to_face, zbuf, bary, dists, s); break;
+        case 4: launch_raster_k<4>(rec, B, F, S, blur_radius, clip_bary, cull_backfaces, perspective_correct, pix_to_face, zbuf, bary, dists, s); break;
+        case 5: launch_raster_k<5>(rec, B, F, S, blur_radius, clip_bary, cull_backfaces, perspective_correct, pix_to_face, zbuf, bary, dists, s); break;
+        case 6: launch_raster_k<6>(rec, B, F, S, blur_radius, clip_bary, cull_backfaces, perspective_correct, pix_to_face, zbuf, bary, dists, s); break;
+        case 7: launch_raster_k<7>(rec, B, F, S, blur_radius, clip_bary, cull_backfaces, perspective_correct, pix_to_face, zbuf, bary, dists, s); break;
+        default: launch_raster_k<8>(rec, B, F, S, blur_radius, clip_bary, cull_backfaces, perspective_correct, pix_to_face, zbuf, bary, dists, s); break;
     }
     ST3D_LAUNCH_CHECK();
     return ST3D_OK;
@@ -460,14 +470,15 @@ extern "C" int st3d_shade_soft_bwd(const float *grad_rgb, const int32_t *pix_to_
 
 extern "C" int st3d_raster_soft_bwd(const float *grad_bary, const float *grad_zbuf, const float *grad_dists,
                                     const int32_t *pix_to_face, const float *verts_ndc, const int32_t *faces, int B, int V,
-                                    int F, int S, int K, int clip_bary, float *grad_verts_ndc, st3d_stream_t stream) {
+                                    int F, int S, int K, int clip_bary, int perspective_correct, float *grad_verts_ndc,
+                                    st3d_stream_t stream) {
     ST3D_CHECK_ARG(pix_to_face && verts_ndc && faces && grad_verts_ndc && (grad_bary || grad_zbuf || grad_dists));
     ST3D_CHECK_ARG(B > 0 && V > 0 && F > 0 && S > 0 && K >= 1);
     hipStream_t s = st3d::as_stream(stream);
     ST3D_HIP(hipMemsetAsync(grad_verts_ndc, 0, (size_t)B * V * 3 * sizeof(float), s));
     const size_t n = (size_t)B * S * S * K;
     raster_k_bwd_kernel<<<st3d::cdiv((long)n, 256), 256, 0, s>>>(grad_bary, grad_zbuf, grad_dists, pix_to_face, verts_ndc, faces, B,
-                                                                  V, S, K, clip_bary, grad_verts_ndc);
+                                                                  V, S, K, clip_bary, perspective_correct, grad_verts_ndc);
     ST3D_LAUNCH_CHECK();
     return ST3D_OK;
 }

@@ -34,14 +34,14 @@ SIGNATURES = {
     "st3d_mesh_reg": (c_int, [c_f32p, c_f32p, c_int, c_i32p, c_int, c_i32p, c_i32p, c_i32p, c_int,
                               ctypes.POINTER(c_float), c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
     "st3d_face_setup": (c_int, [c_f32p, c_i32p, c_int, c_int, c_int, ctypes.c_void_p, c_size, c_stream]),
-    "st3d_raster_soft_fwd": (c_int, [c_f32p, c_int, c_int, c_int, c_int, c_float, c_int, c_i32p, c_f32p, c_f32p, c_f32p,
-                                     c_stream]),
+    "st3d_raster_soft_fwd": (c_int, [c_f32p, c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_int, c_i32p, c_f32p, c_f32p,
+                                     c_f32p, c_stream]),
     "st3d_shade_soft_fwd": (c_int, [c_i32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_int, c_int, c_int, c_int, c_float,
                                     c_float, ctypes.POINTER(c_float), c_f32p, c_f32p, c_stream]),
     "st3d_shade_soft_bwd": (c_int, [c_f32p, c_i32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_int, c_int, c_int, c_int,
                                     c_float, c_float, ctypes.POINTER(c_float), c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
     "st3d_raster_soft_bwd": (c_int, [c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_i32p, c_int, c_int, c_int, c_int, c_int, c_int,
-                                     c_f32p, c_stream]),
+                                     c_int, c_f32p, c_stream]),
     "st3d_apply_background": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_f32p, c_stream]),
     "st3d_conv3x3_packed_floats": (c_size, [c_int, c_int]),
     "st3d_conv3x3_pack": (c_int, [c_f32p, c_int, c_int, c_f32p, c_f32p, c_stream]),
@@ -82,6 +82,7 @@ SIGNATURES = {
     "st3d_plan_set_content_features": (c_int, [ctypes.c_void_p, c_f32p, c_int, c_stream]),
     "st3d_plan_set_style": (c_int, [ctypes.c_void_p, c_f32p, c_int, c_int, c_stream]),
     "st3d_plan_loss": (c_int, [ctypes.c_void_p, c_f32p, c_int, c_int, c_float, c_float, c_f32p, c_f32p, c_stream]),
+    "st3d_plan_backward": (c_int, [ctypes.c_void_p, c_int, c_int, ctypes.POINTER(ctypes.c_void_p), c_f32p, c_stream]),
     "st3d_plan_profile": (c_int, [ctypes.c_void_p, c_int]),
     "st3d_plan_profile_read": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_float), ctypes.POINTER(c_int)]),
     "st3d_plan_profile_launches": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_float), c_int,

@@ -117,7 +117,8 @@ def mesh_reg(verts, target, topo, weights, want_grad=True):
 
 
 # ------------------------------------------------------------------ general soft renderer (K faces per pixel, blur)
-def raster_soft_fwd(verts_ndc, faces_i32, S, K, blur_radius=0.0, clip_bary=None):
+def raster_soft_fwd(verts_ndc, faces_i32, S, K, blur_radius=0.0, clip_bary=None, cull_backfaces=False,
+                    perspective_correct=True):
     """-> pix_to_face (B,S,S,K) int32, zbuf, bary (B,S,S,K,3), dists; clip_bary None = PyTorch3D default (blur > 0)."""
     B, V, _ = verts_ndc.shape
     F = faces_i32.shape[0]
@@ -131,8 +132,8 @@ def raster_soft_fwd(verts_ndc, faces_i32, S, K, blur_radius=0.0, clip_bary=None)
     zbuf = torch.empty((B, S, S, K), dtype=F32, device=dev)
     bary = torch.empty((B, S, S, K, 3), dtype=F32, device=dev)
     dists = torch.empty((B, S, S, K), dtype=F32, device=dev)
-    call("st3d_raster_soft_fwd", dptr(rec), B, F, S, int(K), float(blur_radius), 1 if clip_bary else 0, dptr(p2f), dptr(zbuf),
-         dptr(bary), dptr(dists), stream_ptr())
+    call("st3d_raster_soft_fwd", dptr(rec), B, F, S, int(K), float(blur_radius), 1 if clip_bary else 0,
+         1 if cull_backfaces else 0, 1 if perspective_correct else 0, dptr(p2f), dptr(zbuf), dptr(bary), dptr(dists), stream_ptr())
     return p2f, zbuf, bary, dists
 
 
@@ -168,13 +169,14 @@ def shade_soft_bwd(grad_rgb, frag, verts_uvs, faces_uvs_i32, texture, sigma=1e-4
     return gt, ((gb, gz, gd) if want_geometry else None)
 
 
-def raster_soft_bwd(grads, p2f, verts_ndc, faces_i32, clip_bary):
+def raster_soft_bwd(grads, p2f, verts_ndc, faces_i32, clip_bary, perspective_correct=True):
     gb, gz, gd = grads
     B, V, _ = verts_ndc.shape
     S, K = p2f.shape[1], p2f.shape[3]
     g = torch.empty((B, V, 3), dtype=F32, device=verts_ndc.device)
     call("st3d_raster_soft_bwd", dptr(gb, F32), dptr(gz, F32), dptr(gd, F32), dptr(p2f, I32), dptr(verts_ndc, F32),
-         dptr(faces_i32, I32), B, V, faces_i32.shape[0], S, K, 1 if clip_bary else 0, dptr(g), stream_ptr())
+         dptr(faces_i32, I32), B, V, faces_i32.shape[0], S, K, 1 if clip_bary else 0, 1 if perspective_correct else 0, dptr(g),
+         stream_ptr())
     return g
 
 

@@ -218,9 +218,9 @@ class RotateAxisAngle:
 
 class RasterizationSettings:
     """PyTorch3D RasterizationSettings: image_size, blur_radius, faces_per_pixel, clip_barycentric_coords
-    (None = clip iff blur_radius > 0, the PyTorch3D default).  bin_size / max_faces_per_bin only pick
-    PyTorch3D's binning strategy and are accepted and ignored; perspective_correct must stay on and
-    cull_backfaces off (the values the reference runs with)."""
+    (None = clip iff blur_radius > 0, the PyTorch3D default), perspective_correct (None = True: every camera here is a
+    perspective camera), cull_backfaces.  bin_size / max_faces_per_bin only pick PyTorch3D's binning strategy and are
+    accepted and ignored.  Anything but the reference's own values (first_approach.py:107) runs on the general kernels."""
     MAX_FACES_PER_PIXEL = 8
 
     def __init__(self, image_size=256, blur_radius=0.0, faces_per_pixel=1, bin_size=None, max_faces_per_bin=None,
@@ -229,8 +229,6 @@ class RasterizationSettings:
             if len(image_size) != 2 or image_size[0] != image_size[1]:
                 raise NotImplementedError("square images only")
             image_size = image_size[0]
-        if perspective_correct is False or cull_backfaces:
-            raise NotImplementedError("perspective_correct=False / cull_backfaces=True are not implemented")
         if not 1 <= int(faces_per_pixel) <= self.MAX_FACES_PER_PIXEL:
             raise NotImplementedError(f"faces_per_pixel must be in 1..{self.MAX_FACES_PER_PIXEL}")
         if blur_radius < 0.0:
@@ -238,10 +236,13 @@ class RasterizationSettings:
         self.image_size, self.blur_radius, self.faces_per_pixel = int(image_size), float(blur_radius), int(faces_per_pixel)
         self.clip_barycentric_coords = (self.blur_radius > 0.0) if clip_barycentric_coords is None \
             else bool(clip_barycentric_coords)
+        self.perspective_correct = True if perspective_correct is None else bool(perspective_correct)
+        self.cull_backfaces = bool(cull_backfaces)
 
     @property
     def is_hard(self):
-        return self.faces_per_pixel == 1 and self.blur_radius == 0.0 and not self.clip_barycentric_coords
+        return (self.faces_per_pixel == 1 and self.blur_radius == 0.0 and not self.clip_barycentric_coords
+                and self.perspective_correct and not self.cull_backfaces)
 
 
 class BlendParams:
@@ -319,15 +320,17 @@ class _SoftRenderFn(torch.autograd.Function):
     the vertices; alpha is returned without a gradient (the reference only ever thresholds it, utils.py:72)."""
 
     @staticmethod
-    def forward(ctx, verts, tex_map, faces_i32, verts_uvs, faces_uvs_i32, R, T, S, K, blur, clip, sigma, gamma, bg):
+    def forward(ctx, verts, tex_map, faces_i32, verts_uvs, faces_uvs_i32, R, T, S, K, blur, clip, sigma, gamma, bg,
+                cull=False, persp=True):
         v = verts.detach().to(torch.float32).contiguous()
         tex = tex_map.detach().to(torch.float32).reshape(tex_map.shape[-3], tex_map.shape[-2], 3).contiguous()
         if tex.shape[0] != tex.shape[1]:
             raise NotImplementedError("square texture maps only (the reference resizes to size x size)")
         uvs = verts_uvs.detach().to(torch.float32).reshape(-1, 2).contiguous()
         ndc = ops.project_verts(v, R, T)
-        frag = ops.raster_soft_fwd(ndc, faces_i32, S, K, blur, clip)
+        frag = ops.raster_soft_fwd(ndc, faces_i32, S, K, blur, clip, cull, persp)
         rgb, alpha = ops.shade_soft_fwd(frag, uvs, faces_uvs_i32, tex, sigma, gamma, bg)
+        ctx.persp = persp
         ctx.frag, ctx.uvs, ctx.fuv, ctx.tex = frag, uvs, faces_uvs_i32, tex
         ctx.blend = (sigma, gamma, bg)
         ctx.clip = clip
@@ -348,9 +351,9 @@ class _SoftRenderFn(torch.autograd.Function):
                 gtex = gt.reshape(ctx.tex_shape)
             if need_v:
                 v, ndc, faces_i32, R, T = ctx.geom
-                gndc = ops.raster_soft_bwd(geo, ctx.frag[0], ndc, faces_i32, ctx.clip)
+                gndc = ops.raster_soft_bwd(geo, ctx.frag[0], ndc, faces_i32, ctx.clip, ctx.persp)
                 gverts = ops.project_verts_bwd(v, R, T, gndc).reshape(ctx.verts_shape)
-        return (gverts, gtex) + (None,) * 12
+        return (gverts, gtex) + (None,) * 14
 
 
 def uses_hard_path(raster_settings, blend_params):
@@ -376,7 +379,8 @@ def render_views(meshes, R, T, image_size, raster_settings=None, blend_params=No
     rs = rs if rs is not None else RasterizationSettings(image_size=image_size)
     return _SoftRenderFn.apply(meshes.verts_packed(), tex.maps_padded(), meshes.faces_i32(), tex.verts_uvs_padded(),
                                tex.faces_uvs_i32(), R.to(dev), T.to(dev), int(image_size), rs.faces_per_pixel,
-                               rs.blur_radius, rs.clip_barycentric_coords, bp.sigma, bp.gamma, bp.background_color)
+                               rs.blur_radius, rs.clip_barycentric_coords, bp.sigma, bp.gamma, bp.background_color,
+                               rs.cull_backfaces, rs.perspective_correct)
 
 
 class MeshRenderer:

@@ -143,6 +143,7 @@ class PerceptualPlan:
         self._h = h
         self._content_key = self._style_key = None
         self._content_ref = self._style_ref = None      # the keyed tensors themselves (see _same)
+        self.generation = 0         # bumped by every call that runs a VGG forward in this plan's buffers
         self.loss_buf = torch.zeros((3,), dtype=torch.float32, device=vgg.device)
 
     def close(self):
@@ -157,6 +158,20 @@ class PerceptualPlan:
         imgs = imgs.detach().to(torch.float32).contiguous()
         call("st3d_plan_forward", self._h, dptr(imgs), imgs.shape[0], int(upto), stream_ptr())
         self._n = imgs.shape[0]
+        self.generation += 1
+
+    def backward(self, grads, upto):
+        """{module index: d loss / d (that module's output)} for the images of the LAST forward -> d loss / d images
+        (st3d_plan_backward: the dgrad chain of the loss plan seeded with the caller's tap gradients)."""
+        ptrs = (ctypes.c_void_p * 37)()
+        keep = []
+        for m, g in grads.items():
+            g = g.detach().to(torch.float32).contiguous()
+            keep.append(g)
+            ptrs[int(m)] = g.data_ptr()
+        out = torch.empty((self._n, 3, self.S, self.S), dtype=torch.float32, device=self.vgg.device)
+        call("st3d_plan_backward", self._h, self._n, int(upto), ptrs, dptr(out), stream_ptr())
+        return out
 
     def activation(self, module_idx, n=None):
         """Tensor VIEW of the plan's buffer after `module_idx` (valid until the next forward)."""
@@ -196,6 +211,7 @@ class PerceptualPlan:
         else:
             c = content.detach().to(torch.float32).contiguous()
             call("st3d_plan_set_content", self._h, dptr(c), n, stream_ptr())
+            self.generation += 1
             if self._content_key is not None and self.CONTENT_CACHE > 0:
                 # a second distinct batch showed up: start keeping targets (single-batch runs never pay the copy)
                 feats = torch.empty((n, 512, self.S // 8, self.S // 8), dtype=torch.float32, device=self.vgg.device)
@@ -216,6 +232,7 @@ class PerceptualPlan:
                 sb = 1
             s = s[:1].contiguous() if sb == 1 else s
             call("st3d_plan_set_style", self._h, dptr(s), sb, n, stream_ptr())
+            self.generation += 1
             self._style_key, self._style_ref = k, style
 
     def loss(self, current, style_weight, content_weight, batch_denom=None, want_grad=True):
@@ -225,6 +242,7 @@ class PerceptualPlan:
         grad = torch.empty_like(cur) if want_grad else None
         call("st3d_plan_loss", self._h, dptr(cur), n, int(batch_denom or n), float(style_weight), float(content_weight),
              dptr(self.loss_buf), dptr(grad), stream_ptr())
+        self.generation += 1
         return self.loss_buf, grad
 
     def profile(self, enable):

@@ -32,26 +32,54 @@ _DEFAULT_LAYERS = {
 
 def _fused_ok(image, model):
     return (isinstance(model, _vgg.Vgg19Features) and image.is_cuda and image.dim() == 4 and image.shape[1] == 3
-            and image.shape[2] == image.shape[3] and image.shape[2] % 32 == 0)
+            and image.shape[2] == image.shape[3] and image.shape[2] >= 16)
+
+
+class _FeaturesFn(torch.autograd.Function):
+    """Differentiable taps: forward = the fused plan forward, backward = the plan's input-gradient chain seeded with the
+    gradients the caller's loss sends into the taps (st3d_plan_backward).  The plan keeps the activations the backward
+    needs; if another forward has used its buffers since (``plan.generation``), the forward is redone first."""
+
+    @staticmethod
+    def forward(ctx, image, model, modules):
+        plan = model.plan(image.shape[0], image.shape[2])
+        upto = max(modules)
+        plan.forward(image, upto=upto)
+        ctx.plan, ctx.modules, ctx.upto, ctx.generation = plan, modules, upto, plan.generation
+        ctx.save_for_backward(image)
+        return tuple(plan.activation(m).clone() for m in modules)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        plan = ctx.plan
+        (image,) = ctx.saved_tensors
+        if plan.generation != ctx.generation:
+            plan.forward(image, upto=ctx.upto)
+        given = {m: g for m, g in zip(ctx.modules, grads) if g is not None}
+        return plan.backward(given, ctx.upto), None, None
 
 
 # Extract features using VGG19
 def get_features(image, model, layers=None):
     if layers is None:
         layers = _DEFAULT_LAYERS
-    if _fused_ok(image, model) and not (image.requires_grad and torch.is_grad_enabled()):
-        plan = model.plan(image.shape[0], image.shape[2])
+    if _fused_ok(image, model):
         want = {int(k): v for k, v in layers.items() if k in model._modules}
         features = {}
         if want:
-            plan.forward(image, upto=max(want))
-            for name in model._modules:                      # dict order = module order, as the reference fills it
-                if int(name) in want:
-                    features[want[int(name)]] = plan.activation(int(name)).clone()
+            modules = tuple(int(name) for name in model._modules if int(name) in want)     # module order, as the reference fills it
+            if image.requires_grad and torch.is_grad_enabled():
+                # the reference's own loop body (style_transfer.py:61-83) back-propagates through these
+                outs = _FeaturesFn.apply(image, model, modules)
+            else:
+                plan = model.plan(image.shape[0], image.shape[2])
+                plan.forward(image, upto=max(want))
+                outs = tuple(plan.activation(m).clone() for m in modules)
+            for m, t in zip(modules, outs):
+                features[want[m]] = t
         return features
     if isinstance(model, _vgg.Vgg19Features) and image.requires_grad and torch.is_grad_enabled():
-        raise NotImplementedError("differentiable get_features on the st3d VGG is not exposed; gradients of the "
-                                  "perceptual loss come from compute_perceptual_loss / style_transfer (fused plan)")
+        raise NotImplementedError("differentiable get_features on the st3d VGG needs square (B,3,S,S) GPU images, S >= 16")
     # any other model: the reference's generic walk (each module is whatever the caller built)
     features = {}
     x = image

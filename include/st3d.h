@@ -96,11 +96,13 @@ int st3d_project_verts_bwd(const float *verts, int V, const float *R, const floa
  * RasterizationSettings / BlendParams than the ones the reference constructs at first_approach.py:107-113 and
  * second_approach.py:101-108 (K = 1, blur_radius = 0, default blend, served by the entry points above):
  * K = faces_per_pixel <= 8 nearest faces per pixel, blur_radius >= 0, barycentric clipping (PyTorch3D clips when
- * blur_radius > 0), softmax_rgb_blend over the K layers with sigma / gamma / background (host float[3]).
+ * blur_radius > 0), cull_backfaces, perspective_correct on/off, softmax_rgb_blend over the K layers with sigma / gamma / background (host float[3]).
  * Fragment arrays are (B,S,S,K[,3]), depth-sorted, -1 filled. */
 int st3d_face_setup(const float *verts_ndc, const int32_t *faces, int B, int V, int F, void *face_records,
                     size_t records_bytes /* >= st3d_raster_workspace_bytes */, st3d_stream_t stream);
 int st3d_raster_soft_fwd(const float *face_records, int B, int F, int S, int K, float blur_radius, int clip_bary,
+                         int cull_backfaces /* skip faces whose NDC area is negative */,
+                         int perspective_correct /* 0: screen-space barycentrics */,
                          int32_t *pix_to_face, float *zbuf, float *bary, float *dists, st3d_stream_t stream);
 int st3d_shade_soft_fwd(const int32_t *pix_to_face, const float *bary, const float *zbuf, const float *dists,
                         const float *verts_uvs, const int32_t *faces_uvs, const float *texture, int B, int S, int T,
@@ -116,7 +118,8 @@ int st3d_shade_soft_bwd(const float *grad_rgb, const int32_t *pix_to_face, const
 /* PyTorch3D RasterizeMeshesBackward: (grad_bary, grad_zbuf, grad_dists) -> grad_verts_ndc (B,V,3), zeroed by the call */
 int st3d_raster_soft_bwd(const float *grad_bary, const float *grad_zbuf, const float *grad_dists,
                          const int32_t *pix_to_face, const float *verts_ndc, const int32_t *faces, int B, int V, int F,
-                         int S, int K, int clip_bary, float *grad_verts_ndc, st3d_stream_t stream);
+                         int S, int K, int clip_bary, int perspective_correct, float *grad_verts_ndc,
+                         st3d_stream_t stream);
 
 /* apply_background, utils.py:19-30: out = img*mask + bg*(1-mask); bg (B,3,S,S) or, with
  * bg_batch == 1, one (3,S,S) image broadcast over the batch.  Optional grad path is the
@@ -255,6 +258,13 @@ int st3d_plan_set_style(st3d_plan *plan, const float *style, int style_batch, in
  * sharded over ranks).  loss_out: device float[3] = {total, content_loss, style_loss}. */
 int st3d_plan_loss(st3d_plan *plan, const float *current, int n, int batch_denom, float style_weight,
                    float content_weight, float *loss_out, float *grad_current, st3d_stream_t stream);
+/* Backward of st3d_plan_forward for losses computed OUTSIDE the library on its taps (the reference's own loop body,
+ * style_transfer.py:61-83, calls get_features(optimized_imgs) with grad and back-propagates through it):
+ * grad_modules = host array of 37 device pointers, entry m = d loss / d (output of VGG module m) shaped like
+ * st3d_plan_activation(m) for the n images of the last forward (NULL = none; a conv and the in-place ReLU behind it
+ * are one tensor) -> grad_image (n,3,S,S). */
+int st3d_plan_backward(st3d_plan *plan, int n, int upto_module, const float *const *grad_modules, float *grad_image,
+                       st3d_stream_t stream);
 /* per-kernel-family timing of the next calls (HIP events on the call's stream): enable, then
  * read accumulated milliseconds + launch counts; families: 0 conv_fwd (Winograd launches) 1 conv_dgrad (Winograd)
  * 2 pool 3 gram_fwd 4 gram_bwd 5 loss/elementwise 6 convx_fwd (convs Winograd does not cover: conv1_1, odd shapes)

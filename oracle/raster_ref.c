@@ -430,9 +430,22 @@ void ref_project_verts_bwd(const float *verts, int V, const float *R, const floa
  * (PyTorch3D clips when blur_radius > 0 unless told otherwise): the general form of ref_rasterize
  * the reference does NOT use (it fixes K = 1, blur = 0) but BASELINE.json's north star names.
  * Outputs (S,S,K) sorted by ascending depth, -1 filled.  PARITY UNPINNED (see the header). */
+void ref_rasterize_k2(const float *verts_ndc, const int32_t *faces, int F, int S, int K,
+                      float blur_radius, int clip_bary, int cull_backfaces, int perspective_correct, int nthreads,
+                      int32_t *pix_to_face, float *zbuf, float *bary, float *dists);
+
 void ref_rasterize_k(const float *verts_ndc, const int32_t *faces, int F, int S, int K,
                      float blur_radius, int clip_bary, int nthreads,
                      int32_t *pix_to_face, float *zbuf, float *bary, float *dists)
+{
+    ref_rasterize_k2(verts_ndc, faces, F, S, K, blur_radius, clip_bary, 0, 1, nthreads, pix_to_face, zbuf, bary, dists);
+}
+
+/* ... with RasterizationSettings.cull_backfaces (a face whose signed NDC area is negative is skipped) and
+ * perspective_correct (0: the screen-space barycentrics are used as they are) */
+void ref_rasterize_k2(const float *verts_ndc, const int32_t *faces, int F, int S, int K,
+                      float blur_radius, int clip_bary, int cull_backfaces, int perspective_correct, int nthreads,
+                      int32_t *pix_to_face, float *zbuf, float *bary, float *dists)
 {
     const float pad = sqrtf(blur_radius);
     (void)nthreads;
@@ -456,13 +469,17 @@ void ref_rasterize_k(const float *verts_ndc, const int32_t *faces, int F, int S,
                 if (fmaxf(z0, fmaxf(z1, z2)) < K_EPS) continue;
                 const float face_area = edge_fn(x2, y2, x0, y0, x1, y1);
                 if (face_area <= K_EPS && face_area >= -K_EPS) continue;
+                if (cull_backfaces && face_area < 0.f) continue;
                 const float area = face_area + K_EPS;
                 const float w0 = edge_fn(xf, yf, x1, y1, x2, y2) / area;
                 const float w1 = edge_fn(xf, yf, x2, y2, x0, y0) / area;
                 const float w2 = edge_fn(xf, yf, x0, y0, x1, y1) / area;
-                const float t0 = w0 * z1 * z2, t1 = z0 * w1 * z2, t2 = z0 * z1 * w2;
-                const float den = fmaxf(t0 + t1 + t2, K_EPS);
-                const float b0 = t0 / den, b1 = t1 / den, b2 = t2 / den;
+                float b0 = w0, b1 = w1, b2 = w2;
+                if (perspective_correct) {
+                    const float t0 = w0 * z1 * z2, t1 = z0 * w1 * z2, t2 = z0 * z1 * w2;
+                    const float den = fmaxf(t0 + t1 + t2, K_EPS);
+                    b0 = t0 / den; b1 = t1 / den; b2 = t2 / den;
+                }
                 float c0 = b0, c1 = b1, c2 = b2;
                 if (clip_bary) {
                     c0 = fminf(fmaxf(b0, 0.f), 1.f); c1 = fminf(fmaxf(b1, 0.f), 1.f); c2 = fminf(fmaxf(b2, 0.f), 1.f);

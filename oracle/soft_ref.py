@@ -41,7 +41,7 @@ def project(verts, R, T):
     return torch.stack([s * view[:, 0] / view[:, 2], s * view[:, 1] / view[:, 2], view[:, 2]], dim=1)
 
 
-def soft_geometry(ndc, faces, p2f, S, clip_bary):
+def soft_geometry(ndc, faces, p2f, S, clip_bary, perspective_correct=True):
     """ndc (V,3), faces (F,3) long, p2f (S,S,K) long -> bary (S,S,K,3), zbuf, dists, mask."""
     K = p2f.shape[-1]
     mask = p2f >= 0
@@ -60,7 +60,7 @@ def soft_geometry(ndc, faces, p2f, S, clip_bary):
     w2 = _edge(px, py, x0, y0, x1, y1) / area
     t0, t1, t2 = w0 * z1 * z2, z0 * w1 * z2, z0 * z1 * w2
     den = (t0 + t1 + t2).clamp_min(K_EPS)
-    b = torch.stack([t0 / den, t1 / den, t2 / den], dim=-1)
+    b = torch.stack([t0 / den, t1 / den, t2 / den], dim=-1) if perspective_correct else torch.stack([w0, w1, w2], dim=-1)
     inside = (b > 0).all(dim=-1)
     if clip_bary:
         c = b.clamp(0, 1)
@@ -105,10 +105,11 @@ def softmax_rgb_blend(colors, zbuf, dists, mask, sigma=1e-4, gamma=1e-4, backgro
     return rgb, 1.0 - alpha
 
 
-def soft_render(verts, R, T, faces, p2f, verts_uvs, faces_uvs, tex, S, clip_bary, sigma, gamma, background=(1.0, 1.0, 1.0)):
+def soft_render(verts, R, T, faces, p2f, verts_uvs, faces_uvs, tex, S, clip_bary, sigma, gamma, background=(1.0, 1.0, 1.0),
+                perspective_correct=True):
     """One view, fixed coverage: -> rgb (3,S,S), alpha (S,S); differentiable in verts and tex."""
     ndc = project(verts, R, T)
-    bary, pz, sd, mask = soft_geometry(ndc, faces, p2f, S, clip_bary)
+    bary, pz, sd, mask = soft_geometry(ndc, faces, p2f, S, clip_bary, perspective_correct)
     colors = sample_texture(bary, p2f, verts_uvs, faces_uvs, tex)
     rgb, alpha = softmax_rgb_blend(colors, pz, sd, mask, sigma, gamma, background)
     return rgb.permute(2, 0, 1), alpha

@@ -756,3 +756,95 @@ def test_get_vgg_loads_a_local_torchvision_state_dict(mods, tmp_path, golden_dir
     with pytest.raises(KeyError):
         torch.save({k: v for k, v in state.items() if not k.startswith("28.")}, str(tmp_path / "bad.pth"))
         U.get_vgg(weights=str(tmp_path / "bad.pth"))
+
+
+def test_reference_style_transfer_body_runs_on_differentiable_get_features(mods, vgg, golden_dir):
+    """The reference's own loop body (style_transfer.py:44-83: get_features(optimized_imgs) WITH grad, torch.mean /
+    gram_matrix losses written by the caller, total_loss.backward(), torch.optim.Adam) runs unchanged on the st3d VGG:
+    get_features is an autograd node whose backward is the plan's input-gradient chain.  Checked against the golden G4
+    trajectory produced by the reference's code, and the tap gradients against the fused loss plan."""
+    ST, L, _, dev = mods
+    d = np.load(os.path.join(golden_dir, "g4_style_transfer.npz"))
+    init, con, sty = (torch.from_numpy(d[k]).to(dev) for k in ("init", "con", "sty"))
+    model = vgg
+    # ---- the reference's body, typed against the drop-in names (get_features / gram_matrix / optim)
+    content_features = ST.get_features(con, model)['conv4_2']
+    style_features = ST.get_features(sty, model)
+    style_grams = {layer: ST.gram_matrix(style_features[layer]) for layer in style_features}
+    style_grams.pop('conv4_2')
+    optimized_imgs = init.clone().detach().requires_grad_(True)
+    optimizer = ST.optim.Adam([optimized_imgs], lr=float(d["lr"]))
+    for step in range(int(d["steps"])):
+        feats = ST.get_features(optimized_imgs, model)
+        assert feats['conv1_1'].requires_grad
+        content_loss = torch.mean((feats['conv4_2'] - content_features) ** 2)
+        style_loss = 0
+        for layer in style_grams:
+            f = feats[layer]
+            style_loss += torch.mean((ST.gram_matrix(f) - style_grams[layer]) ** 2) / (f.shape[1] ** 2 * f.shape[2] ** 2)
+        total_loss = 1 * content_loss + 1e6 * style_loss
+        optimizer.zero_grad()
+        total_loss.backward()
+        if step == 0:      # same gradient as the fused plan delivers for the same loss
+            x = init.clone().requires_grad_(True)
+            fused = L.compute_perceptual_loss(x, con, sty, model)
+            fused.backward()
+            assert abs(fused.item() - total_loss.item()) <= 2e-5 * abs(fused.item())
+            assert float((optimized_imgs.grad - x.grad).norm() / x.grad.norm()) <= 2e-5
+        optimizer.step()
+    err = (optimized_imgs.detach().cpu() - torch.from_numpy(d["result"])).abs()
+    assert float(err.max()) <= 1e-4, float(err.max())
+
+
+def test_differentiable_get_features_custom_taps_match_torch_autograd(mods, vgg):
+    """Gradients through taps the loss plan never uses -- a conv that feeds a pool ('2' = conv1_2 -> pool1), the pool
+    itself ('4'), a deep tap ('25') -- at a size off the Winograd path (S = 40: odd 5x5 maps at the bottom), and a backward
+    that happens after ANOTHER forward has reused the plan's buffers: all against torch autograd on the oracle VGG."""
+    ST, _, _, dev = mods
+    from oracle import perceptual_ref as P
+    torch.manual_seed(0)
+    model = P.make_vgg19_features(seed=0).double()
+    layers = {"2": "conv1_2", "4": "pool1", "10": "conv3_1", "25": "conv4_4"}
+    for S, B in ((64, 2), (40, 1)):
+        x = torch.rand(B, 3, S, S)
+        w = {}
+        xg = x.clone().to(dev).requires_grad_(True)
+        feats = ST.get_features(xg, vgg, layers=layers)
+        ST.get_features(torch.rand(B, 3, S, S).to(dev), vgg)          # clobbers the plan's activations before the backward
+        loss = 0
+        for k, f in feats.items():
+            w[k] = torch.randn(f.shape, generator=torch.Generator().manual_seed(len(k)))
+            loss = loss + (f * w[k].to(dev)).sum()
+        loss.backward()
+        # reference: fp64 autograd through the SAME ReLU gates and max-pool selections the kernels saw.  An activation
+        # within rounding of 0, or two window elements within rounding of each other, resolve differently in fp64, and
+        # with random-sign tap gradients one such unit moves its whole receptive field by O(1) (observed: one pool2 window)
+        with torch.no_grad():
+            acts = {n: t.cpu() for n, t in ST.get_features(x.to(dev), vgg, layers={str(i): str(i) for i in range(26)}).items()}
+        xr = x.clone().double().requires_grad_(True)
+        cur, ref_loss = xr, 0
+        for name, layer in model._modules.items():
+            if int(name) > 26:
+                break
+            if isinstance(layer, torch.nn.ReLU):
+                cur = cur * (acts[str(int(name) - 1)] > 0).double()       # a conv tap IS its post-ReLU output
+                if str(int(name) - 1) in layers:                      # conv taps are post-ReLU (in-place ReLU)
+                    ref_loss = ref_loss + (cur * w[layers[str(int(name) - 1)]].double()).sum()
+            elif isinstance(layer, torch.nn.MaxPool2d):
+                pre, pooled = acts[str(int(name) - 1)], acts[name]
+                Hp, Wp = pooled.shape[2:]
+                taken, out = torch.zeros_like(pooled, dtype=torch.bool), 0
+                for k in range(4):                                    # first maximum in row-major window order
+                    dy, dx = k >> 1, k & 1
+                    sel = (pre[:, :, dy:2 * Hp:2, dx:2 * Wp:2] == pooled) & ~taken
+                    taken |= sel
+                    out = out + cur[:, :, dy:2 * Hp:2, dx:2 * Wp:2] * sel.double()
+                cur = out
+                if name in layers:
+                    ref_loss = ref_loss + (cur * w[layers[name]].double()).sum()
+            else:
+                cur = layer(cur)
+        ref_loss.backward()
+        assert abs(float(loss.detach()) - float(ref_loss.detach())) <= 1e-4 * abs(float(ref_loss.detach()))
+        rel = float((xg.grad.cpu().double() - xr.grad).norm() / xr.grad.norm())
+        assert rel <= 1e-4, (S, rel)

@@ -481,6 +481,74 @@ def test_soft_shade_forward_and_backward_match_oracle(dev, ops, cow, K, blur, si
     assert rel_v <= 5e-5, rel_v
 
 
+@pytest.mark.parametrize("K,blur,cull,persp", [(1, 0.0, True, True), (2, 0.0, False, False), (4, 5e-4, True, False)])
+def test_soft_raster_cull_backfaces_and_perspective_correct_flags(dev, ops, cow, K, blur, cull, persp):
+    """RasterizationSettings.cull_backfaces / perspective_correct=False on the general kernels: fragments bit-exact vs
+    the C oracle; the vertex gradient without perspective correction against fp64 autograd at the same coverage."""
+    from oracle import render_ref as rr
+    from oracle import soft_ref as SR
+    S, B = 72, 2
+    R, T = _cams(B, seed=11 + K)
+    clip = blur > 0
+    verts = torch.from_numpy(cow["verts"]).to(dev)
+    faces = torch.from_numpy(cow["faces"]).to(dev)
+    Rd, Td = torch.from_numpy(R).to(dev), torch.from_numpy(T).to(dev)
+    ndc = ops.project_verts(verts, Rd, Td)
+    frag = ops.raster_soft_fwd(ndc, faces, S, K, blur, clip, cull_backfaces=cull, perspective_correct=persp)
+    for b in range(B):
+        ref = rr.rasterize_k(rr.project_verts(cow["verts"], R[b], T[b]), cow["faces"], S, K, blur, clip, nthreads=8,
+                             cull_backfaces=cull, perspective_correct=persp)
+        for got, want in zip(frag, ref):
+            np.testing.assert_array_equal(got[b].cpu().numpy(), want)
+    plain = ops.raster_soft_fwd(ndc, faces, S, K, blur, clip)
+    if cull and K == 1:
+        assert torch.equal(plain[0], frag[0])                   # closed mesh seen from outside: nearest faces are front faces
+    if not persp:
+        assert not torch.equal(plain[2], frag[2])
+        rng = np.random.default_rng(0)
+        gb = torch.from_numpy(rng.standard_normal((B, S, S, K, 3)).astype(np.float32)).to(dev)
+        gz = torch.from_numpy(rng.standard_normal((B, S, S, K)).astype(np.float32)).to(dev)
+        gd = torch.zeros_like(gz)
+        gndc = ops.raster_soft_bwd((gb, gz, gd), frag[0], ndc, faces, clip, perspective_correct=False)
+        fc = torch.from_numpy(cow["faces"]).long()
+        for b in range(B):
+            nd = ndc[b].cpu().double().requires_grad_(True)
+            p2f = frag[0][b].cpu().long()
+            bary64, pz64, _, m64 = SR.soft_geometry(nd, fc, p2f, S, clip, perspective_correct=False)
+            md = m64.double()
+            ((bary64 * gb[b].cpu().double() * md.unsqueeze(-1)).sum() + (pz64 * gz[b].cpu().double() * md).sum()).backward()
+            rel = float((gndc[b].cpu().double() - nd.grad).norm() / nd.grad.norm())
+            assert rel <= 5e-5, rel
+
+
+def test_renderer_routes_non_default_raster_flags_to_the_general_kernels(dev, cow):
+    """MeshRenderer with cull_backfaces=True or perspective_correct=False (K = 1, blur 0) leaves the specialised path; the
+    culled render of the closed cow equals the default render, the uncorrected one differs and back-propagates."""
+    import utils as U
+    from st3d.render import FoVPerspectiveCameras, MeshRasterizer, MeshRenderer, RasterizationSettings, SoftPhongShader
+    U.device = dev
+    S = 64
+    R, T = _cams(2, seed=3)
+    rng = np.random.default_rng(5)
+    tex = torch.from_numpy(rng.random((1, 32, 32, 3), dtype=np.float32)).to(dev).requires_grad_(True)
+    verts = torch.from_numpy(cow["verts"]).to(dev).requires_grad_(True)
+    mesh = U.build_mesh(torch.from_numpy(cow["verts_uvs"])[None].to(dev), torch.from_numpy(cow["faces_uvs"].astype(np.int64))[None].to(dev),
+                        tex, verts, torch.from_numpy(cow["faces"].astype(np.int64)).to(dev))
+    cams = FoVPerspectiveCameras(R=torch.from_numpy(R), T=torch.from_numpy(T), device=dev)
+    mk = lambda **kw: MeshRenderer(MeshRasterizer(None, RasterizationSettings(image_size=S, **kw)), SoftPhongShader())
+    base, culled, flat = mk(), mk(cull_backfaces=True), mk(perspective_correct=False)
+    assert base.is_hard and not culled.is_hard and not flat.is_hard
+    with torch.no_grad():
+        a, ma = base.render(mesh, cams)
+        c, mc = culled.render(mesh, cams)
+    np.testing.assert_allclose(c.cpu().numpy(), a.cpu().numpy(), atol=2e-6)
+    assert torch.equal(mc > 0, ma > 0)
+    f, _ = flat.render(mesh, cams)
+    assert float((f.detach() - a).abs().max()) > 1e-3
+    f.sum().backward()
+    assert torch.isfinite(verts.grad).all() and float(verts.grad.abs().sum()) > 0 and float(tex.grad.abs().sum()) > 0
+
+
 def _crop_ref(x, y0, x0, h, halo, fn):
     """fn (a stack of pad-1 convolutions needing `halo` pixels of context) on the crop [y0,y0+h) x [x0,x0+h) of the
     image x (1,C,S,S): evaluated on the crop + halo clipped to the image -- zero padding at the region edge is the true

@@ -161,8 +161,10 @@ def test_raster_settings_and_blend_params_validation():
     assert soft.image_size == 64 and soft.clip_barycentric_coords and not soft.is_hard
     assert not RasterizationSettings(blur_radius=1e-4, clip_barycentric_coords=False).clip_barycentric_coords
     assert not uses_hard_path(rs, BlendParams(sigma=1e-3)) and not uses_hard_path(rs, BlendParams(background_color=(0, 0, 0)))
-    for bad in (dict(faces_per_pixel=0), dict(faces_per_pixel=9), dict(blur_radius=-1.0), dict(cull_backfaces=True),
-                dict(perspective_correct=False), dict(image_size=(64, 32))):
+    for general in (dict(cull_backfaces=True), dict(perspective_correct=False)):      # supported, on the general kernels
+        assert not RasterizationSettings(**general).is_hard and not uses_hard_path(RasterizationSettings(**general), None)
+    assert RasterizationSettings(perspective_correct=None).perspective_correct          # PyTorch3D: None -> True for perspective cameras
+    for bad in (dict(faces_per_pixel=0), dict(faces_per_pixel=9), dict(blur_radius=-1.0), dict(image_size=(64, 32))):
         with pytest.raises((NotImplementedError, ValueError)):
             RasterizationSettings(**bad)
     with pytest.raises(ValueError):

@@ -63,3 +63,53 @@ def test_blend_weights_two_layers():
     z2 = torch.tensor([[[1.0, 2.0]]])
     rgb2, _ = SR.softmax_rgb_blend(colors, z2, d, m, sigma=1e-2, gamma=1e-4)
     assert float(rgb2[0, 0, 0]) > 0.99 and float(rgb2[0, 0, 2]) < 0.01
+
+
+def test_cull_backfaces_sign_convention_and_closed_mesh(cow):
+    """RasterizationSettings.cull_backfaces skips faces whose signed NDC area is negative.  (a) one triangle, both
+    windings: exactly one of them survives culling, and it is the one whose vertices run counter-clockwise as SEEN in the
+    image (NDC +X points left, SURVEY.md A.1, so that is the winding with positive edge-function area); (b) the cow
+    -- a closed, outward-wound mesh viewed from outside -- loses only hidden layers: the nearest face of every pixel is
+    front-facing, so the K = 1 result is identical with and without culling, while the second layer (the far side of the
+    body) disappears."""
+    S = 24
+    v = np.array([[-0.5, -0.5, 2.0], [0.5, -0.5, 2.0], [0.0, 0.6, 2.0]], np.float32)
+    ccw, cw = np.array([[0, 1, 2]], np.int32), np.array([[0, 2, 1]], np.int32)
+    area = (v[2, 0] - v[0, 0]) * (v[1, 1] - v[0, 1]) - (v[2, 1] - v[0, 1]) * (v[1, 0] - v[0, 0])     # edge_fn(v2; v0, v1)
+    assert area < 0                                                      # this order is "back-facing" by the rule
+    keep_a = rr.rasterize_k(v, ccw, S, 1, 0.0, cull_backfaces=True)[0]
+    keep_b = rr.rasterize_k(v, cw, S, 1, 0.0, cull_backfaces=True)[0]
+    both = rr.rasterize_k(v, ccw, S, 1, 0.0)[0]
+    assert (both >= 0).sum() > 30 and (keep_a >= 0).sum() == 0
+    np.testing.assert_array_equal(keep_b, rr.rasterize_k(v, cw, S, 1, 0.0)[0])
+    R, T = rr.look_at_view_transform(2.10, [20.0, -35.0], [30.0, 200.0], at=(0, 0.10, 0.25))
+    for b in range(2):
+        ndc = rr.project_verts(cow["verts"], R[b], T[b])
+        off = rr.rasterize_k(ndc, cow["faces"], 64, 2, 0.0, nthreads=4)
+        on = rr.rasterize_k(ndc, cow["faces"], 64, 2, 0.0, nthreads=4, cull_backfaces=True)
+        for x, y in zip(off, on):
+            np.testing.assert_array_equal(x[:, :, 0], y[:, :, 0])
+        assert (off[0][..., 1] >= 0).sum() > 5 * max((on[0][..., 1] >= 0).sum(), 1)
+
+
+def test_perspective_correct_off_gives_screen_space_barycentrics():
+    """A triangle with vertex depths 1, 2, 4: at the pixel nearest its screen-space centroid the uncorrected barycentrics
+    are the edge-function weights (~1/3 each, depth ~ their plain mean); with perspective correction they are weighted
+    by 1/z_i (b_i ~ (1/z_i) / sum 1/z_j, depth = harmonic interpolation)."""
+    S = 33
+    v = np.array([[-0.6, -0.5, 1.0], [0.6, -0.5, 2.0], [0.0, 0.7, 4.0]], np.float32)
+    f = np.array([[0, 2, 1]], np.int32)
+    yi, xi = np.unravel_index(np.argmin([[(1 - (2 * x + 1) / S - 0.0) ** 2 + (1 - (2 * y + 1) / S + 0.1) ** 2 for x in range(S)]
+                                         for y in range(S)]), (S, S))
+    px, py = 1 - (2 * xi + 1) / S, 1 - (2 * yi + 1) / S
+    p2f0, z0, b0, _ = rr.rasterize_k(v, f, S, 1, 0.0, perspective_correct=False)
+    p2f1, z1, b1, _ = rr.rasterize_k(v, f, S, 1, 0.0, perspective_correct=True)
+    np.testing.assert_array_equal(p2f0, p2f1)                            # coverage does not depend on the correction
+    w = b0[yi, xi, 0]
+    verts2 = v[f[0]]
+    np.testing.assert_allclose((w[:, None] * verts2[:, :2]).sum(0), [px, py], atol=1e-6)      # screen-space interpolation
+    assert abs(z0[yi, xi, 0] - float((w * verts2[:, 2]).sum())) < 1e-6
+    want = w / verts2[:, 2]
+    want /= want.sum()
+    np.testing.assert_allclose(b1[yi, xi, 0], want, atol=1e-6)
+    assert abs(z1[yi, xi, 0] - 1.0 / float((w / verts2[:, 2]).sum())) < 1e-5
