@@ -20,7 +20,10 @@
 // LDS with a sign early-out before the six divisions, one 8x8 quadrant per wave with wave-level culling.
 // Algorithmic bytes per view = F*52 + S*S*24 written.  Built with -ffp-contract=off so the arithmetic
 // is the same operation sequence as oracle/raster_ref.c (bit-comparable).
+#include <type_traits>
+
 #include "common.h"
+#include "det.h"
 
 namespace {
 
@@ -283,15 +286,25 @@ namespace {
 // atomics per (tile, face) goes out -- ~20x fewer L2 atomics than one set per pixel, all of them contended.
 constexpr int kBwdSlots = 512;          // > 256 pixels: the probe always terminates
 
+// DET 0: float LDS table + float global atomics.  DET 1: bound pass of the deterministic variant (partials[block] = sum of
+// the absolute contributions of the block's pixels).  DET 2: the same binning in 64-bit fixed point with the scale derived
+// from that bound (det.h): `gndc` is then the int64 accumulator array.
+template <int DET>
 __global__ __launch_bounds__(256) void raster_bwd_kernel(const float *__restrict__ gbary, const int32_t *__restrict__ p2f,
                                                          const float *__restrict__ ndc, const int32_t *__restrict__ faces,
-                                                         int B, int V, int S, int tiles_x, float *__restrict__ gndc) {
+                                                         int B, int V, int S, int tiles_x, float *__restrict__ gndc,
+                                                         const st3d_det::DetHeader *__restrict__ det, float *__restrict__ partials) {
+    typedef typename std::conditional<DET == 2, unsigned long long, float>::type acc_t;
     __shared__ int s_key[kBwdSlots];
-    __shared__ float s_acc[kBwdSlots][9];
+    __shared__ acc_t s_acc[DET == 1 ? 1 : kBwdSlots][9];
+    __shared__ float s4[4];
     const int tid = threadIdx.x;
-    for (int e = tid; e < kBwdSlots; e += 256) s_key[e] = -1;
-    for (int e = tid; e < kBwdSlots * 9; e += 256) (&s_acc[0][0])[e] = 0.f;
-    __syncthreads();
+    if (DET != 1) {
+        for (int e = tid; e < kBwdSlots; e += 256) s_key[e] = -1;
+        for (int e = tid; e < kBwdSlots * 9; e += 256) (&s_acc[0][0])[e] = (acc_t)0;
+        __syncthreads();
+    }
+    const double dscale = DET == 2 ? det->scale : 1.0;
     const int b = blockIdx.y;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int yi = ty * 16 + (tid >> 4), xi = tx * 16 + (tid & 15);
@@ -299,6 +312,7 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(const float *__restrict
     const float *vb = ndc + (size_t)b * V * 3;
     int f = -1;
     size_t i = 0;
+    float bound = 0.f;
     if (yi < S && xi < S) { i = (size_t)b * HW + (size_t)yi * S + xi; f = p2f[i]; }
     if (f >= 0) {
         const float px = pix_to_ndc(S - 1 - xi, S), py = pix_to_ndc(S - 1 - yi, S);
@@ -323,32 +337,50 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(const float *__restrict
             const float dz2 = dt0 * w0 * z1 + dt1 * z0 * w1;
             const float de0 = dw0 / A, de1 = dw1 / A, de2 = dw2 / A;
             const float dA = -(dw0 * w0 + dw1 * w1 + dw2 * w2) / A;
-            const float gx0 = de1 * -(py - y2) + de2 * (py - y1) + dA * (y2 - y1);
-            const float gy0 = de1 * (px - x2) + de2 * (x1 - px) + dA * (x1 - x2);
-            const float gx1 = de0 * (py - y2) + de2 * -(py - y0) + dA * -(y2 - y0);
-            const float gy1 = de0 * (x2 - px) + de2 * (px - x0) + dA * (x2 - x0);
-            const float gx2 = de0 * -(py - y1) + de1 * (py - y0) + dA * (y1 - y0);
-            const float gy2 = de0 * (px - x1) + de1 * (x0 - px) + dA * -(x1 - x0);
-            int slot = (int)(((unsigned)f * 2654435761u) >> 23) & (kBwdSlots - 1);
-            for (;;) {
-                const int prev = atomicCAS(&s_key[slot], -1, f);
-                if (prev == -1 || prev == f) break;
-                slot = (slot + 1) & (kBwdSlots - 1);
+            float c9[9];
+            c9[0] = de1 * -(py - y2) + de2 * (py - y1) + dA * (y2 - y1);
+            c9[1] = de1 * (px - x2) + de2 * (x1 - px) + dA * (x1 - x2);
+            c9[2] = dz0;
+            c9[3] = de0 * (py - y2) + de2 * -(py - y0) + dA * -(y2 - y0);
+            c9[4] = de0 * (x2 - px) + de2 * (px - x0) + dA * (x2 - x0);
+            c9[5] = dz1;
+            c9[6] = de0 * -(py - y1) + de1 * (py - y0) + dA * (y1 - y0);
+            c9[7] = de0 * (px - x1) + de1 * (x0 - px) + dA * -(x1 - x0);
+            c9[8] = dz2;
+            if (DET == 1) {
+#pragma unroll
+                for (int c = 0; c < 9; ++c) bound += fabsf(c9[c]);
+            } else {
+                int slot = (int)(((unsigned)f * 2654435761u) >> 23) & (kBwdSlots - 1);
+                for (;;) {
+                    const int prev = atomicCAS(&s_key[slot], -1, f);
+                    if (prev == -1 || prev == f) break;
+                    slot = (slot + 1) & (kBwdSlots - 1);
+                }
+#pragma unroll
+                for (int c = 0; c < 9; ++c) {
+                    if (DET == 2) atomicAdd(reinterpret_cast<unsigned long long *>(&s_acc[slot][c]),
+                                            (unsigned long long)st3d_det::det_quantise(c9[c], dscale));
+                    else atomicAdd(reinterpret_cast<float *>(&s_acc[slot][c]), c9[c]);
+                }
             }
-            float *a = s_acc[slot];
-            atomicAdd(a + 0, gx0); atomicAdd(a + 1, gy0); atomicAdd(a + 2, dz0);
-            atomicAdd(a + 3, gx1); atomicAdd(a + 4, gy1); atomicAdd(a + 5, dz1);
-            atomicAdd(a + 6, gx2); atomicAdd(a + 7, gy2); atomicAdd(a + 8, dz2);
         }
     }
+    if (DET == 1) {
+        const float t = st3d_det::det_block_sum(bound, s4);
+        if (tid == 0) partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = t;
+        return;
+    }
     __syncthreads();
-    float *gb = gndc + (size_t)b * V * 3;
     for (int e = tid; e < kBwdSlots * 9; e += 256) {
         const int slot = e / 9, c = e - slot * 9;
         const int fk = s_key[slot];
         if (fk < 0) continue;
-        const float v = s_acc[slot][c];
-        if (v != 0.f) atomicAdd(gb + 3 * faces[3 * fk + c / 3] + (c % 3), v);
+        const acc_t v = s_acc[slot][c];
+        if (v == (acc_t)0) continue;
+        const size_t o = (size_t)b * V * 3 + 3 * (size_t)faces[3 * fk + c / 3] + (c % 3);
+        if (DET == 2) atomicAdd(reinterpret_cast<unsigned long long *>(gndc) + o, (unsigned long long)v);
+        else atomicAdd(gndc + o, (float)v);
     }
 }
 
@@ -385,8 +417,41 @@ extern "C" int st3d_raster_bwd(const float *grad_bary, const int32_t *pix_to_fac
     hipStream_t s = st3d::as_stream(stream);
     ST3D_HIP(hipMemsetAsync(grad_verts_ndc, 0, (size_t)B * V * 3 * sizeof(float), s));
     const int tiles = (S + 15) / 16;
-    raster_bwd_kernel<<<dim3(tiles * tiles, B), 256, 0, s>>>(grad_bary, pix_to_face, verts_ndc, faces, B, V, S, tiles,
-                                                             grad_verts_ndc);
+    raster_bwd_kernel<0><<<dim3(tiles * tiles, B), 256, 0, s>>>(grad_bary, pix_to_face, verts_ndc, faces, B, V, S, tiles,
+                                                                grad_verts_ndc, nullptr, nullptr);
+    ST3D_LAUNCH_CHECK();
+    return ST3D_OK;
+}
+
+extern "C" size_t st3d_raster_bwd_det_workspace_bytes(int B, int V, int S) {
+    const size_t tiles = (size_t)((S + 15) / 16);
+    return st3d_det::workspace_bytes((size_t)B * V * 3, tiles * tiles * B);
+}
+
+// st3d_raster_bwd with a bitwise reproducible result (fixed-point accumulation, det.h): a first pass bounds the partial
+// sums, the second accumulates; about twice the time of the float-atomic version.
+extern "C" int st3d_raster_bwd_det(const float *grad_bary, const int32_t *pix_to_face, const float *verts_ndc,
+                                   const int32_t *faces, int B, int V, int F, int S, float *grad_verts_ndc, void *workspace,
+                                   size_t workspace_bytes, st3d_stream_t stream) {
+    ST3D_CHECK_ARG(grad_bary && pix_to_face && verts_ndc && faces && grad_verts_ndc && workspace);
+    ST3D_CHECK_ARG(B > 0 && V > 0 && F > 0 && S > 0);
+    ST3D_CHECK_ARG(workspace_bytes >= st3d_raster_bwd_det_workspace_bytes(B, V, S) && ((uintptr_t)workspace & 15) == 0);
+    hipStream_t s = st3d::as_stream(stream);
+    const int tiles = (S + 15) / 16;
+    const size_t np = (size_t)tiles * tiles * B, nacc = (size_t)B * V * 3;
+    auto *hdr = reinterpret_cast<st3d_det::DetHeader *>(workspace);
+    float *partials = st3d_det::partials_of(workspace);
+    long long *acc = st3d_det::accum_of(workspace, np);
+    raster_bwd_kernel<1><<<dim3(tiles * tiles, B), 256, 0, s>>>(grad_bary, pix_to_face, verts_ndc, faces, B, V, S, tiles, nullptr,
+                                                                nullptr, partials);
+    ST3D_LAUNCH_CHECK();
+    st3d_det::det_scale_kernel<<<1, 256, 0, s>>>(partials, (int)np, hdr);
+    ST3D_LAUNCH_CHECK();
+    ST3D_HIP(hipMemsetAsync(acc, 0, nacc * sizeof(long long), s));
+    raster_bwd_kernel<2><<<dim3(tiles * tiles, B), 256, 0, s>>>(grad_bary, pix_to_face, verts_ndc, faces, B, V, S, tiles,
+                                                                reinterpret_cast<float *>(acc), hdr, nullptr);
+    ST3D_LAUNCH_CHECK();
+    st3d_det::det_convert_kernel<<<st3d::cdiv((long)nacc, 256), 256, 0, s>>>(acc, nacc, hdr, 0, grad_verts_ndc);
     ST3D_LAUNCH_CHECK();
     return ST3D_OK;
 }

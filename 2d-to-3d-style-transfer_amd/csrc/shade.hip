@@ -9,7 +9,10 @@
 // HBM-bound: algorithmic bytes per pixel = 24 B fragments + 16 B written (fwd),
 // 24 + 12 B read (bwd) + <= 12 float atomics per covered pixel into the 3*T*T*4-byte map.
 // Built with -ffp-contract=off (same operation sequence as oracle/raster_ref.c).
+#include <type_traits>
+
 #include "common.h"
+#include "det.h"
 
 namespace {
 
@@ -98,18 +101,25 @@ __global__ __launch_bounds__(256) void shade_fwd_kernel(const int32_t *__restric
 // path) are per-pixel outputs written directly.
 constexpr int kTexSlots = 2048;          // >= 4 x 256 footprint corners: the probe always terminates
 
+// DET 0: float LDS table + float global atomics (fast default).  DET 1: the same binning in 64-bit fixed point (LDS and
+// global integer atomics; `gtex` is then the int64 accumulator array and `det` holds the power-of-two scale): bitwise
+// reproducible whatever the order (det.h).
+template <int DET>
 __global__ __launch_bounds__(256) void shade_bwd_kernel(const float *__restrict__ grad_rgb, const int32_t *__restrict__ p2f,
                                                         const float *__restrict__ bary, const float *__restrict__ zbuf,
                                                         const float *__restrict__ dists, const float *__restrict__ uvs,
                                                         const int32_t *__restrict__ fuv, const float *__restrict__ tex,
                                                         int B, int S, int T, int tiles_x, float *__restrict__ gtex,
-                                                        float *__restrict__ guv, float *__restrict__ gbary) {
+                                                        float *__restrict__ guv, float *__restrict__ gbary,
+                                                        const st3d_det::DetHeader *__restrict__ det) {
+    typedef typename std::conditional<DET != 0, unsigned long long, float>::type acc_t;
     __shared__ int s_key[kTexSlots];
-    __shared__ float s_acc[kTexSlots][3];
+    __shared__ acc_t s_acc[kTexSlots][3];
     const int tid = threadIdx.x;
+    const double dscale = DET ? det->scale : 1.0;
     if (gtex) {
         for (int e = tid; e < kTexSlots; e += 256) s_key[e] = -1;
-        for (int e = tid; e < kTexSlots * 3; e += 256) (&s_acc[0][0])[e] = 0.f;
+        for (int e = tid; e < kTexSlots * 3; e += 256) (&s_acc[0][0])[e] = (acc_t)0;
         __syncthreads();
     }
     const size_t HW = (size_t)S * S;
@@ -162,7 +172,16 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(const float *__restrict_
                     if (prev == -1 || prev == texel) break;
                     slot = (slot + 1) & (kTexSlots - 1);
                 }
-                atomicAdd(&s_acc[slot][0], gk[0] * w); atomicAdd(&s_acc[slot][1], gk[1] * w); atomicAdd(&s_acc[slot][2], gk[2] * w);
+                if (DET) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        atomicAdd(reinterpret_cast<unsigned long long *>(&s_acc[slot][c]),
+                                  (unsigned long long)st3d_det::det_quantise(gk[c] * w, dscale));
+                } else {
+                    atomicAdd(reinterpret_cast<float *>(&s_acc[slot][0]), gk[0] * w);
+                    atomicAdd(reinterpret_cast<float *>(&s_acc[slot][1]), gk[1] * w);
+                    atomicAdd(reinterpret_cast<float *>(&s_acc[slot][2]), gk[2] * w);
+                }
             };
             if (q.vy0 && q.vx0) deposit(e00, w00);
             if (q.vy0 && q.vx1) deposit(e01, w01);
@@ -176,8 +195,10 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(const float *__restrict_
             const int slot = e / 3, c = e - slot * 3;
             const int texel = s_key[slot];
             if (texel < 0) continue;
-            const float v = s_acc[slot][c];
-            if (v != 0.f) atomicAdd(gtex + (size_t)texel * 3 + c, v);
+            const acc_t v = s_acc[slot][c];
+            if (v == (acc_t)0) continue;
+            if (DET) atomicAdd(reinterpret_cast<unsigned long long *>(gtex) + (size_t)texel * 3 + c, (unsigned long long)v);
+            else atomicAdd(gtex + (size_t)texel * 3 + c, (float)v);
         }
     }
 }
@@ -218,8 +239,56 @@ extern "C" int st3d_shade_bwd(const float *grad_rgb, const int32_t *pix_to_face,
     ST3D_CHECK_ARG(B > 0 && S > 0 && T > 1 && F > 0 && VT > 0);
     const size_t n = (size_t)B * S * S;
     const int tiles = (S + 15) / 16;
-    shade_bwd_kernel<<<dim3(tiles * tiles, B), 256, 0, st3d::as_stream(stream)>>>(
-        grad_rgb, pix_to_face, bary, zbuf, dists, verts_uvs, faces_uvs, texture, B, S, T, tiles, grad_texture, grad_uv, grad_bary);
+    shade_bwd_kernel<0><<<dim3(tiles * tiles, B), 256, 0, st3d::as_stream(stream)>>>(
+        grad_rgb, pix_to_face, bary, zbuf, dists, verts_uvs, faces_uvs, texture, B, S, T, tiles, grad_texture, grad_uv, grad_bary,
+        nullptr);
+    ST3D_LAUNCH_CHECK();
+    return ST3D_OK;
+}
+
+namespace {
+// bound on any texel-channel sum: sum over the batch of |grad_rgb| (blend weight and bilinear weights are <= 1)
+__global__ __launch_bounds__(256) void abs_sum_kernel(const float *__restrict__ x, size_t n, float *__restrict__ partials) {
+    __shared__ float s4[4];
+    float acc = 0.f;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) acc += fabsf(x[i]);
+    const float t = st3d_det::det_block_sum(acc, s4);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+constexpr int kDetPartials = 1024;
+}  // namespace
+
+extern "C" size_t st3d_shade_bwd_det_workspace_bytes(int T) {
+    return st3d_det::workspace_bytes((size_t)T * T * 3, kDetPartials);
+}
+
+// st3d_shade_bwd with a bitwise reproducible texture gradient: fixed-point accumulation (det.h); ~2-3x the time of the
+// float-atomic scatter.  grad_texture is ACCUMULATED into, like st3d_shade_bwd.
+extern "C" int st3d_shade_bwd_det(const float *grad_rgb, const int32_t *pix_to_face, const float *bary, const float *zbuf,
+                                  const float *dists, const float *verts_uvs, const int32_t *faces_uvs, const float *texture,
+                                  int B, int S, int T, int F, int VT, float *grad_texture, float *grad_uv, float *grad_bary,
+                                  void *workspace, size_t workspace_bytes, st3d_stream_t stream) {
+    ST3D_CHECK_ARG(grad_rgb && pix_to_face && bary && zbuf && dists && verts_uvs && faces_uvs && texture && workspace);
+    ST3D_CHECK_ARG(grad_texture);
+    ST3D_CHECK_ARG(B > 0 && S > 0 && T > 1 && F > 0 && VT > 0);
+    ST3D_CHECK_ARG(workspace_bytes >= st3d_shade_bwd_det_workspace_bytes(T) && ((uintptr_t)workspace & 15) == 0);
+    hipStream_t s = st3d::as_stream(stream);
+    auto *hdr = reinterpret_cast<st3d_det::DetHeader *>(workspace);
+    float *partials = st3d_det::partials_of(workspace);
+    long long *acc = st3d_det::accum_of(workspace, kDetPartials);
+    const size_t npx = (size_t)B * 3 * S * S, nacc = (size_t)T * T * 3;
+    abs_sum_kernel<<<kDetPartials, 256, 0, s>>>(grad_rgb, npx, partials);
+    ST3D_LAUNCH_CHECK();
+    st3d_det::det_scale_kernel<<<1, 256, 0, s>>>(partials, kDetPartials, hdr);
+    ST3D_LAUNCH_CHECK();
+    ST3D_HIP(hipMemsetAsync(acc, 0, nacc * sizeof(long long), s));
+    const int tiles = (S + 15) / 16;
+    shade_bwd_kernel<1><<<dim3(tiles * tiles, B), 256, 0, s>>>(grad_rgb, pix_to_face, bary, zbuf, dists, verts_uvs, faces_uvs,
+                                                                texture, B, S, T, tiles, reinterpret_cast<float *>(acc), grad_uv,
+                                                                grad_bary, hdr);
+    ST3D_LAUNCH_CHECK();
+    st3d_det::det_convert_kernel<<<st3d::cdiv((long)nacc, 256), 256, 0, s>>>(acc, nacc, hdr, 1, grad_texture);
     ST3D_LAUNCH_CHECK();
     return ST3D_OK;
 }

@@ -29,6 +29,12 @@ SIGNATURES = {
                                c_f32p, c_f32p, c_stream]),
     "st3d_shade_bwd": (c_int, [c_f32p, c_i32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_int, c_int, c_int, c_int,
                                c_int, c_f32p, c_f32p, c_f32p, c_stream]),
+    "st3d_shade_bwd_det_workspace_bytes": (c_size, [c_int]),
+    "st3d_shade_bwd_det": (c_int, [c_f32p, c_i32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_int, c_int, c_int, c_int,
+                                   c_int, c_f32p, c_f32p, c_f32p, ctypes.c_void_p, c_size, c_stream]),
+    "st3d_raster_bwd_det_workspace_bytes": (c_size, [c_int, c_int, c_int]),
+    "st3d_raster_bwd_det": (c_int, [c_f32p, c_i32p, c_f32p, c_i32p, c_int, c_int, c_int, c_int, c_f32p, ctypes.c_void_p, c_size,
+                                    c_stream]),
     "st3d_raster_bwd": (c_int, [c_f32p, c_i32p, c_f32p, c_i32p, c_int, c_int, c_int, c_int, c_f32p, c_stream]),
     "st3d_project_verts_bwd": (c_int, [c_f32p, c_int, c_f32p, c_f32p, c_int, c_float, c_f32p, c_int, c_f32p, c_stream]),
     "st3d_mesh_reg": (c_int, [c_f32p, c_f32p, c_int, c_i32p, c_int, c_i32p, c_i32p, c_i32p, c_int,

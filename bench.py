@@ -335,6 +335,9 @@ def main():
                 "shade_fwd": (time_ms(lambda: ops.shade_fwd(frag, vuv, fuv, tex2)), px * (24.0 + 16.0)),
                 "shade_bwd_texture_scatter": (time_ms(lambda: ops.shade_bwd(gimg, frag, vuv, fuv, tex2)), px * (24.0 + 12.0) + 2 * tex2.numel() * 4.0),
             }
+            ops.set_deterministic(False)
+            hb["shade_bwd_texture_scatter_float_atomics"] = (time_ms(lambda: ops.shade_bwd(gimg, frag, vuv, fuv, tex2)), px * (24.0 + 12.0) + 2 * tex2.numel() * 4.0)
+            ops.set_deterministic(True)
             if st is not None:
                 gdummy = torch.zeros_like(tex2)
                 pdummy, m1, m2 = tex2.clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone()

@@ -92,6 +92,21 @@ int st3d_project_verts_bwd(const float *verts, int V, const float *R, const floa
                            float inv_tan_half_fov, const float *grad_verts_ndc, int accumulate,
                            float *grad_verts, st3d_stream_t stream);
 
+/* ---- bitwise reproducible variants of the two gradient scatters ("deterministic variant").
+ * The default kernels sum with float atomics, so the last bits of the texture / vertex gradient depend on the order
+ * the hardware serves them; these accumulate in 64-bit fixed point with a power-of-two scale taken from a bound on the
+ * partial sums (integer addition is associative: any order gives the same bits), then convert.  Same arguments and
+ * results (to fp32 rounding of the final sums) as st3d_shade_bwd / st3d_raster_bwd, plus a caller-owned workspace. */
+size_t st3d_shade_bwd_det_workspace_bytes(int T);
+int st3d_shade_bwd_det(const float *grad_rgb, const int32_t *pix_to_face, const float *bary, const float *zbuf,
+                       const float *dists, const float *verts_uvs, const int32_t *faces_uvs, const float *texture,
+                       int B, int S, int T, int F, int VT, float *grad_texture /* accumulated into */, float *grad_uv,
+                       float *grad_bary, void *workspace, size_t workspace_bytes, st3d_stream_t stream);
+size_t st3d_raster_bwd_det_workspace_bytes(int B, int V, int S);
+int st3d_raster_bwd_det(const float *grad_bary, const int32_t *pix_to_face, const float *verts_ndc, const int32_t *faces,
+                        int B, int V, int F, int S, float *grad_verts_ndc, void *workspace, size_t workspace_bytes,
+                        st3d_stream_t stream);
+
 /* ---- general soft renderer: PyTorch3D's MeshRasterizer / SoftPhongShader under any other
  * RasterizationSettings / BlendParams than the ones the reference constructs at first_approach.py:107-113 and
  * second_approach.py:101-108 (K = 1, blur_radius = 0, default blend, served by the entry points above):
