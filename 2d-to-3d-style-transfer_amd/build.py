@@ -33,6 +33,7 @@ SOURCES = {
     "loss.hip": ["-ffp-contract=off"],
     "mesh.hip": [],
     "plan.hip": [],
+    "comm.hip": [],
 }
 
 
@@ -66,7 +67,7 @@ def build(force=False, jobs=4, verbose=True):
         with ThreadPoolExecutor(max_workers=max(1, jobs)) as ex:
             list(ex.map(run, todo))
     if todo or not os.path.exists(SO):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs)
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs + ["-ldl"])
     return SO
 
 

@@ -294,6 +294,22 @@ int st3d_plan_profile_read(st3d_plan *plan, float *ms_out /*host [ST3D_PROFILE_F
 int st3d_plan_profile_launches(st3d_plan *plan, int *tags_out /*host [capacity]*/, float *ms_out /*host [capacity]*/,
                                int capacity, int *count_out);
 
+/* ------------------------------------------------------------------ multi-GPU
+ * One process per GPU; every rank renders / VGGs its slice of the view batch with the loss means divided by the GLOBAL
+ * batch (batch_denom of st3d_plan_loss) and ONE SUM all-reduce of the flat fp32 gradient (3*T*T texture floats
+ * [+ 3*V vertex floats]) makes the gradients identical everywhere before the replicated st3d_adam_step.  The reference
+ * has no multi-GPU path (no torch.distributed / NCCL call site anywhere); the Python host of this package goes through
+ * torch.distributed (backend "nccl" = RCCL on ROCm) -- these entry points give a C caller the same collective: RCCL's
+ * ncclAllReduce over xGMI, bound at run time (no link-time dependency).  Rank 0 creates the id and hands the 128 bytes to
+ * the other ranks by any out-of-band means (file, env, socket); each rank then calls st3d_comm_init with its HIP
+ * device current. */
+#define ST3D_COMM_ID_BYTES 128
+typedef struct st3d_comm st3d_comm;
+int st3d_comm_unique_id(unsigned char id_out[ST3D_COMM_ID_BYTES]);
+int st3d_comm_init(st3d_comm **out, int rank, int world, const unsigned char unique_id[ST3D_COMM_ID_BYTES]);
+int st3d_allreduce_sum_f32(st3d_comm *comm, float *buf /* device, in place */, size_t n, st3d_stream_t stream);
+int st3d_comm_destroy(st3d_comm *comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -81,3 +81,27 @@ def test_two_ranks_reproduce_the_single_rank_run_for_target_both(cow, golden_dir
     assert (diff > 2e-4).mean() <= 0.01
     assert diff.max() <= 6 * 0.002 + 1e-6                       # never more than the steps taken (6 or 8 at lr 0.002 ... )
     assert np.abs(t1 - t2).max() <= 3
+
+
+def test_c_abi_collective_world_of_one():
+    """st3d_comm_* (include/st3d.h): RCCL bound at run time, communicator of one rank on this GPU, in-place SUM all-reduce
+    of a texture-gradient-sized buffer (3 MiB) = identity; argument errors are reported, not crashed.  The N > 1 case
+    needs one GPU per rank: the driver's 8-GPU bench exercises the same ncclAllReduce through torch.distributed."""
+    import ctypes
+    from st3d import _lib
+    from st3d._lib import call, dptr, stream_ptr
+    lib = _lib.load()
+    uid = ctypes.create_string_buffer(128)
+    call("st3d_comm_unique_id", uid)
+    assert any(uid.raw)
+    h = ctypes.c_void_p()
+    assert lib.st3d_comm_init(ctypes.byref(h), 1, 1, uid) == -1 and b"invalid argument" in lib.st3d_last_error()
+    call("st3d_comm_init", ctypes.byref(h), 0, 1, uid)
+    x = torch.rand(512 * 512 * 3, device="cuda:0")
+    y = x.clone()
+    for _ in range(3):
+        call("st3d_allreduce_sum_f32", h, dptr(y), y.numel(), stream_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(x, y)
+    assert lib.st3d_allreduce_sum_f32(h, None, 4, None) == -1
+    call("st3d_comm_destroy", h)
