@@ -12,7 +12,12 @@ def last_step(path, counter):
     rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     adam = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
-    return rows[adam[-2] + 1:adam[-1] + 1]
+    # the last pair of Adam launches with a whole optimiser step (conv launches) between them: bench.py times a few
+    # kernels on their own after the steps, Adam among them
+    for a, b in reversed(list(zip(adam[:-1], adam[1:]))):
+        if any("wino" in r["Kernel_Name"] or "conv3x3_kernel" in r["Kernel_Name"] for r in rows[a + 1:b]):
+            return rows[a + 1:b + 1]
+    raise SystemExit("no optimiser step found in " + path)
 
 
 def short(name):
@@ -33,7 +38,7 @@ with open(prefix + "_per_dispatch.csv", "w") as fh:
         f, w = float(a["Counter_Value"]), float(b["Counter_Value"])
         fh.write("%s,%s,%.0f,%.0f\n" % (short(a["Kernel_Name"]).replace(",", ";"), a.get("Grid_Size", ""), f, w))
         tot_f += f * 1024; tot_w += w * 1024
-        if "wino_kernel" in a["Kernel_Name"]:
+        if "wino" in a["Kernel_Name"] and "pack" not in a["Kernel_Name"]:
             wino_f += f * 1024; wino_w += w * 1024; nwino += 1
 out = {
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 2 --warmup 1 "
