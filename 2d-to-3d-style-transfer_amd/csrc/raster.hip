@@ -80,8 +80,12 @@ __device__ __forceinline__ void pixel_span(float cmin, float cmax, int S, int &l
     lo = (int)floorf(a) - 1; hi = (int)ceilf(b) + 1;
 }
 
+// near_flag (optional): set when a face that will be rasterised has a vertex nearer than z_clip -- PyTorch3D would clip or
+// drop it (z_clip_value = znear / 2); this specialised path does not clip, so the host turns the flag into an error that
+// points at the general kernels (soft.hip), which do.
 __global__ void face_setup_kernel(const float *__restrict__ ndc, const int32_t *__restrict__ faces, int B, int V, int F,
-                                  float4 *__restrict__ rec, int S, int Fp, unsigned *__restrict__ words) {
+                                  float4 *__restrict__ rec, int S, int Fp, unsigned *__restrict__ words, float z_clip,
+                                  int32_t *__restrict__ near_flag) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int stride = words ? Fp : F;
     if (i >= B * stride) return;
@@ -95,6 +99,7 @@ __global__ void face_setup_kernel(const float *__restrict__ ndc, const int32_t *
     const float zmax = fmaxf(z0, fmaxf(z1, z2));
     const float area = edge_fn(x2, y2, x0, y0, x1, y1);
     const bool valid = !(zmax < kEps) && !(area <= kEps && area >= -kEps);
+    if (near_flag && valid && fminf(z0, fminf(z1, z2)) < z_clip) atomicOr(near_flag, 1);
     const size_t o = (size_t)b * F + f;
     rec[3 * o + 0] = make_float4(x0, y0, z0, x1);
     rec[3 * o + 1] = make_float4(y1, z1, x2, y2);
@@ -250,14 +255,14 @@ extern "C" int st3d_face_setup(const float *verts_ndc, const int32_t *faces, int
     ST3D_CHECK_ARG(B > 0 && V > 0 && F > 0 && records_bytes >= st3d_raster_workspace_bytes(B, F));
     ST3D_CHECK_ARG(((uintptr_t)face_records & 15) == 0);
     face_setup_kernel<<<st3d::cdiv((long)B * F, 256), 256, 0, st3d::as_stream(stream)>>>(
-        verts_ndc, faces, B, V, F, reinterpret_cast<float4 *>(face_records), 0, F, nullptr);
+        verts_ndc, faces, B, V, F, reinterpret_cast<float4 *>(face_records), 0, F, nullptr, 0.f, nullptr);
     ST3D_LAUNCH_CHECK();
     return ST3D_OK;
 }
 
 extern "C" int st3d_raster_fwd(const float *verts_ndc, const int32_t *faces, int B, int V, int F, int S, void *workspace,
                                size_t workspace_bytes, int32_t *pix_to_face, float *zbuf, float *bary, float *dists,
-                               st3d_stream_t stream) {
+                               float z_clip, int32_t *near_flag, st3d_stream_t stream) {
     ST3D_CHECK_ARG(verts_ndc && faces && workspace && pix_to_face && zbuf && bary && dists);
     ST3D_CHECK_ARG(B > 0 && V > 0 && F > 0 && S > 0 && S <= 4096);       // 8-bit tile indices in the packed ranges
     ST3D_CHECK_ARG(workspace_bytes >= st3d_raster_workspace_bytes(B, F));
@@ -266,7 +271,7 @@ extern "C" int st3d_raster_fwd(const float *verts_ndc, const int32_t *faces, int
     float4 *rec = reinterpret_cast<float4 *>(workspace);
     const int Fp = (F + 1) & ~1;
     unsigned *words = reinterpret_cast<unsigned *>(rec + (size_t)B * F * 3);
-    face_setup_kernel<<<st3d::cdiv((long)B * Fp, 256), 256, 0, s>>>(verts_ndc, faces, B, V, F, rec, S, Fp, words);
+    face_setup_kernel<<<st3d::cdiv((long)B * Fp, 256), 256, 0, s>>>(verts_ndc, faces, B, V, F, rec, S, Fp, words, z_clip, near_flag);
     ST3D_LAUNCH_CHECK();
     const int tiles = st3d::cdiv(S, TILE);
     raster_tile_kernel<<<dim3(tiles, tiles, B), 256, 0, s>>>(rec, words, F, Fp, S, pix_to_face, zbuf, bary, dists);

@@ -37,12 +37,113 @@ __device__ __forceinline__ float pld2(float px, float py, float ax, float ay, fl
     return dx * dx + dy * dy;
 }
 
-// face records as in raster.hip: [x0 y0 z0 x1][y1 z1 x2 y2][z2 valid 0 0]
+// ------------------------------------------------------------------------------------------ near-plane clipping
+// PyTorch3D clips every mesh against z = z_clip_value (znear / 2 for perspective cameras) before rasterising
+// (renderer/mesh/clip.py; oracle/raster_ref.c:ref_clip_face is the CPU restatement, same operation order): a face with one
+// vertex behind the plane becomes the quadrilateral p4 p2 p3 p5 = triangles t1 (p4, p2, p5) and t2 (p5, p2, p3), with two
+// behind the triangle (p1, p4, p5), with three behind nothing.  Two record slots per face: 2 f (the face itself, t1, or the
+// two-behind triangle) and 2 f + 1 (t2).  code: 0 empty, 1 unclipped, 2 + p1 + 3 * kind (kind 0 = t1, 1 = t2, 2 = two behind).
+struct Clipped { float t[2][9]; int code[2]; float w2, w3; };
+
+__device__ __forceinline__ void clip_face_dev(const float v[9], float z_clip, int persp, Clipped &o) {
+    o.code[0] = o.code[1] = 0; o.w2 = o.w3 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { o.t[0][k] = 0.f; o.t[1][k] = 0.f; }
+    const bool b0 = v[2] < z_clip, b1 = v[5] < z_clip, b2 = v[8] < z_clip;
+    const int nb = (int)b0 + (int)b1 + (int)b2;
+    if (nb == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) o.t[0][k] = v[k];
+        o.code[0] = 1;
+        return;
+    }
+    if (nb == 3) return;
+    const bool lone = (nb == 1);                   // the vertex alone on its side of the plane
+    const int i1 = (b0 == lone) ? 0 : ((b1 == lone) ? 1 : 2);      // (the host restatement keeps the LAST match; one match exists)
+    const int i2 = (i1 + 1) % 3, i3 = (i1 + 2) % 3;
+    float p1[3], p2[3], p3[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        p1[k] = i1 == 0 ? v[k] : (i1 == 1 ? v[3 + k] : v[6 + k]);
+        p2[k] = i2 == 0 ? v[k] : (i2 == 1 ? v[3 + k] : v[6 + k]);
+        p3[k] = i3 == 0 ? v[k] : (i3 == 1 ? v[3 + k] : v[6 + k]);
+    }
+    const float w2 = (p1[2] - z_clip) / (p1[2] - p2[2]);
+    const float w3 = (p1[2] - z_clip) / (p1[2] - p3[2]);
+    float p4[3], p5[3];
+    if (persp) {
+        p4[0] = ((1.0f - w2) * (p1[0] * p1[2]) + w2 * (p2[0] * p2[2])) / z_clip;
+        p4[1] = ((1.0f - w2) * (p1[1] * p1[2]) + w2 * (p2[1] * p2[2])) / z_clip;
+        p5[0] = ((1.0f - w3) * (p1[0] * p1[2]) + w3 * (p3[0] * p3[2])) / z_clip;
+        p5[1] = ((1.0f - w3) * (p1[1] * p1[2]) + w3 * (p3[1] * p3[2])) / z_clip;
+    } else {
+        p4[0] = (1.0f - w2) * p1[0] + w2 * p2[0]; p4[1] = (1.0f - w2) * p1[1] + w2 * p2[1];
+        p5[0] = (1.0f - w3) * p1[0] + w3 * p3[0]; p5[1] = (1.0f - w3) * p1[1] + w3 * p3[1];
+    }
+    p4[2] = z_clip; p5[2] = z_clip;
+    o.w2 = w2; o.w3 = w3;
+    if (nb == 1) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            o.t[0][k] = p4[k]; o.t[0][3 + k] = p2[k]; o.t[0][6 + k] = p5[k];
+            o.t[1][k] = p5[k]; o.t[1][3 + k] = p2[k]; o.t[1][6 + k] = p3[k];
+        }
+        o.code[0] = 2 + i1; o.code[1] = 2 + i1 + 3;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { o.t[0][k] = p1[k]; o.t[0][3 + k] = p4[k]; o.t[0][6 + k] = p5[k]; }
+        o.code[0] = 2 + i1 + 6;
+    }
+}
+
+// out = c . M, M = rows of barycentric coordinates (in the original face) of the clipped triangle's vertices:
+//   t1 (kind 0) rows (b4, b2, b5); t2 (kind 1) rows (b5, b2, b3); two-behind (kind 2) rows (b1, b4, b5)
+//   b4 = (1 - w2) e_i1 + w2 e_i2, b5 = (1 - w3) e_i1 + w3 e_i3.  Written out per original vertex in the summation order
+//   (row0 + row1) + row2 of the CPU restatement (products with the matrix's zeros and ones are exact and omitted).
+__device__ __forceinline__ void clip_convert(int code, float w2, float w3, float c0, float c1, float c2, float out[3]) {
+    if (code <= 1) { out[0] = c0; out[1] = c1; out[2] = c2; return; }
+    const int i1 = (code - 2) % 3, kind = (code - 2) / 3, i2 = (i1 + 1) % 3, i3 = (i1 + 2) % 3;
+    float e1, e2, e3;
+    if (kind == 0) { e1 = c0 * (1.0f - w2) + c2 * (1.0f - w3); e2 = c0 * w2 + c1; e3 = c2 * w3; }
+    else if (kind == 1) { e1 = c0 * (1.0f - w3); e2 = c1; e3 = c0 * w3 + c2; }
+    else { e1 = (c0 + c1 * (1.0f - w2)) + c2 * (1.0f - w3); e2 = c1 * w2; e3 = c2 * w3; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) out[k] = (k == i1) ? e1 : ((k == i2) ? e2 : e3);
+}
+
+// record: [x0 y0 z0 x1][y1 z1 x2 y2][z2 code w2 w3]; two per face
+__global__ void face_setup_clip_kernel(const float *__restrict__ ndc, const int32_t *__restrict__ faces, int B, int V, int F,
+                                       float z_clip, int persp, float4 *__restrict__ rec) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * F) return;
+    const int b = i / F, f = i - b * F;
+    const float *vb = ndc + (size_t)b * V * 3;
+    const int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
+    const float v[9] = {vb[3 * i0], vb[3 * i0 + 1], vb[3 * i0 + 2], vb[3 * i1], vb[3 * i1 + 1], vb[3 * i1 + 2],
+                        vb[3 * i2], vb[3 * i2 + 1], vb[3 * i2 + 2]};
+    Clipped c;
+    clip_face_dev(v, z_clip, persp, c);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const float *t = c.t[s];
+        const float zmax = fmaxf(t[2], fmaxf(t[5], t[8]));
+        const float area = edge_fn(t[6], t[7], t[0], t[1], t[3], t[4]);
+        const bool valid = c.code[s] != 0 && !(zmax < kEps) && !(area <= kEps && area >= -kEps);
+        const size_t o = ((size_t)b * F + f) * 2 + s;
+        rec[3 * o + 0] = make_float4(t[0], t[1], t[2], t[3]);
+        rec[3 * o + 1] = make_float4(t[4], t[5], t[6], t[7]);
+        rec[3 * o + 2] = make_float4(t[8], valid ? (float)c.code[s] : 0.f, c.w2, c.w3);
+    }
+}
+
+// face records as in raster.hip: [x0 y0 z0 x1][y1 z1 x2 y2][z2 valid 0 0]; with clipping two per face (rpf = 2), see above
 template <int K>
 __global__ __launch_bounds__(256) void raster_k_kernel(const float4 *__restrict__ rec, int F, int S, float blur, int clip,
-                                                       int cull, int persp, int32_t *__restrict__ pix_to_face, float *__restrict__ zbuf,
-                                                       float *__restrict__ bary, float *__restrict__ dists) {
-    __shared__ float s_face[LIST_CAP][9];
+                                                       int cull, int persp, int rpf, int32_t *__restrict__ pix_to_face,
+                                                       float *__restrict__ zbuf, float *__restrict__ bary,
+                                                       float *__restrict__ dists, int32_t *__restrict__ frag_slot) {
+    // F counts RECORDS here (rpf per face: 2 with near-plane clipping, else 1)
+    __shared__ float s_face[LIST_CAP][10];
     __shared__ int s_fidx[LIST_CAP];
     __shared__ int s_wcnt[4];
 
@@ -84,6 +185,7 @@ __global__ __launch_bounds__(256) void raster_k_kernel(const float4 *__restrict_
             s_face[slot][0] = r0.x; s_face[slot][1] = r0.y; s_face[slot][2] = r0.z;
             s_face[slot][3] = r0.w; s_face[slot][4] = r1.x; s_face[slot][5] = r1.y;
             s_face[slot][6] = r1.z; s_face[slot][7] = r1.w; s_face[slot][8] = r2.x;
+            s_face[slot][9] = r2.y;                     // record code (clipping: which kind of sub-triangle)
         }
         count += total;
         __syncthreads();
@@ -118,6 +220,26 @@ __global__ __launch_bounds__(256) void raster_k_kernel(const float4 *__restrict_
                 const bool inside = (b0 > 0.f) && (b1 > 0.f) && (b2 > 0.f);
                 const float d = fminf(pld2(xf, yf, x0, y0, x1, y1), fminf(pld2(xf, yf, x1, y1, x2, y2), pld2(xf, yf, x2, y2, x0, y0)));
                 if (!inside && d >= blur) continue;
+                if (rpf == 2) {
+                    // the other half of a split quadrilateral already in the list?  keep the one nearer in the image plane
+                    const int code = (int)s_face[i][9];
+                    if (code >= 2 && code < 8) {
+                        const int other = s_fidx[i] ^ 1;
+                        int at = -1;
+#pragma unroll
+                        for (int k = 0; k < K; ++k) if (qf[k] == other) at = k;
+                        if (at >= 0) {
+                            float od = 0.f;
+#pragma unroll
+                            for (int k = 0; k < K; ++k) if (k == at) od = qd[k];
+                            if (!(d < fabsf(od))) continue;
+#pragma unroll
+                            for (int k = 0; k + 1 < K; ++k)
+                                if (k >= at) { qf[k] = qf[k + 1]; qz[k] = qz[k + 1]; qd[k] = qd[k + 1]; qb0[k] = qb0[k + 1]; qb1[k] = qb1[k + 1]; qb2[k] = qb2[k + 1]; }
+                            qf[K - 1] = -1; qz[K - 1] = 3.0e38f; qd[K - 1] = -1.f; qb0[K - 1] = qb1[K - 1] = qb2[K - 1] = -1.f;
+                        }
+                    }
+                }
                 if (!(pz < qz[K - 1])) continue;          // not among the K nearest (ties keep the earlier face)
                 // sorted insertion, fully unrolled: the list stays in registers
                 // (once the new fragment is placed every later slot shifts unconditionally, so equal-z entries
@@ -143,10 +265,21 @@ __global__ __launch_bounds__(256) void raster_k_kernel(const float4 *__restrict_
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const bool ok = qf[k] >= 0;
-        pix_to_face[p + k] = qf[k];
         zbuf[p + k] = ok ? qz[k] : -1.f;
         dists[p + k] = qd[k];
-        bary[3 * (p + k)] = qb0[k]; bary[3 * (p + k) + 1] = qb1[k]; bary[3 * (p + k) + 2] = qb2[k];
+        if (rpf == 2) {                     // back to the original face: index, and barycentrics through the clip's matrix
+            float o3[3] = {qb0[k], qb1[k], qb2[k]};
+            if (ok) {
+                const float4 r2 = rb[3 * (size_t)qf[k] + 2];
+                clip_convert((int)r2.y, r2.z, r2.w, qb0[k], qb1[k], qb2[k], o3);
+            }
+            pix_to_face[p + k] = ok ? (qf[k] >> 1) : -1;
+            bary[3 * (p + k)] = o3[0]; bary[3 * (p + k) + 1] = o3[1]; bary[3 * (p + k) + 2] = o3[2];
+        } else {
+            pix_to_face[p + k] = qf[k];
+            bary[3 * (p + k)] = qb0[k]; bary[3 * (p + k) + 1] = qb1[k]; bary[3 * (p + k) + 2] = qb2[k];
+        }
+        if (frag_slot) frag_slot[p + k] = qf[k];
     }
 }
 
@@ -311,7 +444,8 @@ __global__ __launch_bounds__(256) void raster_k_bwd_kernel(const float *__restri
                                                            const float *__restrict__ gdist, const int32_t *__restrict__ p2f,
                                                            const float *__restrict__ ndc, const int32_t *__restrict__ faces,
                                                            int B, int V, int S, int K, int clip, int persp,
-                                                           float *__restrict__ gndc) {
+                                                           float *__restrict__ gndc, const int32_t *__restrict__ frag_slot,
+                                                           float z_clip) {
     const size_t HW = (size_t)S * S;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)B * HW * K) return;
@@ -323,9 +457,21 @@ __global__ __launch_bounds__(256) void raster_k_bwd_kernel(const float *__restri
     const float px = pix_to_ndc(S - 1 - xi, S), py = pix_to_ndc(S - 1 - yi, S);
     const float *vb = ndc + b * (size_t)V * 3;
     const int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
-    const float x0 = vb[3 * i0], y0 = vb[3 * i0 + 1], z0 = vb[3 * i0 + 2];
-    const float x1 = vb[3 * i1], y1 = vb[3 * i1 + 1], z1 = vb[3 * i1 + 2];
-    const float x2 = vb[3 * i2], y2 = vb[3 * i2 + 1], z2 = vb[3 * i2 + 2];
+    float x0 = vb[3 * i0], y0 = vb[3 * i0 + 1], z0 = vb[3 * i0 + 2];
+    float x1 = vb[3 * i1], y1 = vb[3 * i1 + 1], z1 = vb[3 * i1 + 2];
+    float x2 = vb[3 * i2], y2 = vb[3 * i2 + 1], z2 = vb[3 * i2 + 2];
+    // near-plane clipping: the fragment lives on a clipped sub-triangle of the face; redo the clip (same arithmetic as
+    // face_setup_clip_kernel), differentiate on the sub-triangle, then carry the gradient back to the face's vertices
+    const float ov[9] = {x0, y0, z0, x1, y1, z1, x2, y2, z2};
+    int ccode = 1; float cw2 = 0.f, cw3 = 0.f;
+    if (frag_slot) {
+        Clipped cl;
+        clip_face_dev(ov, z_clip, persp, cl);
+        const int sub = frag_slot[i] & 1;
+        ccode = cl.code[sub]; cw2 = cl.w2; cw3 = cl.w3;
+        x0 = cl.t[sub][0]; y0 = cl.t[sub][1]; z0 = cl.t[sub][2]; x1 = cl.t[sub][3]; y1 = cl.t[sub][4]; z1 = cl.t[sub][5];
+        x2 = cl.t[sub][6]; y2 = cl.t[sub][7]; z2 = cl.t[sub][8];
+    }
     const float A = edge_fn(x2, y2, x0, y0, x1, y1) + kEps;
     const float w0 = edge_fn(px, py, x1, y1, x2, y2) / A;
     const float w1 = edge_fn(px, py, x2, y2, x0, y0) / A;
@@ -343,9 +489,20 @@ __global__ __launch_bounds__(256) void raster_k_bwd_kernel(const float *__restri
         c0 /= s; c1 /= s; c2 /= s;
     }
     const float gzk = gzb ? gzb[i] : 0.f;
-    float dc0 = (gbary ? gbary[3 * i] : 0.f) + gzk * z0;
-    float dc1 = (gbary ? gbary[3 * i + 1] : 0.f) + gzk * z1;
-    float dc2 = (gbary ? gbary[3 * i + 2] : 0.f) + gzk * z2;
+    float gq0 = gbary ? gbary[3 * i] : 0.f, gq1 = gbary ? gbary[3 * i + 1] : 0.f, gq2 = gbary ? gbary[3 * i + 2] : 0.f;
+    const float go[3] = {gq0, gq1, gq2};             // d loss / d (barycentrics in the ORIGINAL face)
+    int k1 = 0, k2 = 1, k3 = 2, kind = -1;
+    if (ccode > 1) {                                 // bary_orig = c . M  =>  d c = M . g
+        k1 = (ccode - 2) % 3; kind = (ccode - 2) / 3; k2 = (k1 + 1) % 3; k3 = (k1 + 2) % 3;
+        const float g1 = go[k1], g2 = go[k2], g3 = go[k3];
+        const float g4 = (1.0f - cw2) * g1 + cw2 * g2, g5 = (1.0f - cw3) * g1 + cw3 * g3;
+        if (kind == 0) { gq0 = g4; gq1 = g2; gq2 = g5; }
+        else if (kind == 1) { gq0 = g5; gq1 = g2; gq2 = g3; }
+        else { gq0 = g1; gq1 = g4; gq2 = g5; }
+    }
+    float dc0 = gq0 + gzk * z0;
+    float dc1 = gq1 + gzk * z1;
+    float dc2 = gq2 + gzk * z2;
     dz0 += gzk * c0; dz1 += gzk * c1; dz2 += gzk * c2;
     float db0 = dc0, db1 = dc1, db2 = dc2;
     if (clip) {
@@ -401,36 +558,105 @@ __global__ __launch_bounds__(256) void raster_k_bwd_kernel(const float *__restri
         else { gx2 += gax; gy2 += gay; gx0 += gbx; gy0 += gby; }
     }
     float *gb = gndc + b * (size_t)V * 3;
+    if (ccode > 1) {
+        // sub-triangle vertices q0 q1 q2 -> the face's p1 p2 p3 (indices k1 k2 k3 in the face) through p4 = cut(p1, p2, w2),
+        // p5 = cut(p1, p3, w3), w2 = (z1 - zc) / (z1 - z2), w3 likewise; M's dependence on w2 / w3 included
+        const float gq[3][3] = {{gx0, gy0, dz0}, {gx1, gy1, dz1}, {gx2, gy2, dz2}};
+        float gp[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};      // [p1, p2, p3][x, y, z]
+        const float P[3][3] = {{ov[3 * k1], ov[3 * k1 + 1], ov[3 * k1 + 2]}, {ov[3 * k2], ov[3 * k2 + 1], ov[3 * k2 + 2]},
+                               {ov[3 * k3], ov[3 * k3 + 1], ov[3 * k3 + 2]}};
+        float dw2 = 0.f, dw3 = 0.f;
+        // which sub-triangle vertex is what: 0 = p1, 1 = p2, 2 = p3, 4 = p4, 5 = p5
+        const int who[3] = {kind == 0 ? 4 : (kind == 1 ? 5 : 0), kind == 2 ? 4 : 1, kind == 1 ? 2 : 5};
+        // the clipped (and possibly clamped / renormalised) coordinates c the forward multiplied into M
+        float cc0 = b0, cc1 = b1, cc2 = b2;
+        if (clip) { cc0 = c0; cc1 = c1; cc2 = c2; }
+        const float cq[3] = {cc0, cc1, cc2};
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int wq = who[q];
+            if (wq < 3) {
+                gp[wq][0] += gq[q][0]; gp[wq][1] += gq[q][1]; gp[wq][2] += gq[q][2];
+            } else {
+                const int o = (wq == 4) ? 1 : 2;                 // the edge's far end: p2 for p4, p3 for p5
+                const float w = (wq == 4) ? cw2 : cw3;
+                float dw = 0.f;
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {                    // x, y
+                    const float g = gq[q][a];
+                    if (persp) {
+                        gp[0][a] += g * (1.0f - w) * P[0][2] / z_clip; gp[0][2] += g * (1.0f - w) * P[0][a] / z_clip;
+                        gp[o][a] += g * w * P[o][2] / z_clip;          gp[o][2] += g * w * P[o][a] / z_clip;
+                        dw += g * (P[o][a] * P[o][2] - P[0][a] * P[0][2]) / z_clip;
+                    } else {
+                        gp[0][a] += g * (1.0f - w); gp[o][a] += g * w;
+                        dw += g * (P[o][a] - P[0][a]);
+                    }
+                }
+                // M's row for this vertex: (1 - w) e_p1 + w e_far
+                dw += cq[q] * (go[(wq == 4) ? k2 : k3] - go[k1]);
+                if (wq == 4) dw2 += dw; else dw3 += dw;
+            }
+        }
+        const float d12 = P[0][2] - P[1][2], d13 = P[0][2] - P[2][2];
+        gp[0][2] += dw2 * (z_clip - P[1][2]) / (d12 * d12) + dw3 * (z_clip - P[2][2]) / (d13 * d13);
+        gp[1][2] += dw2 * (P[0][2] - z_clip) / (d12 * d12);
+        gp[2][2] += dw3 * (P[0][2] - z_clip) / (d13 * d13);
+        const int vi[3] = {i0, i1, i2};
+        const int ks[3] = {k1, k2, k3};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int vtx = vi[ks[r]];
+            atomicAdd(gb + 3 * vtx, gp[r][0]); atomicAdd(gb + 3 * vtx + 1, gp[r][1]); atomicAdd(gb + 3 * vtx + 2, gp[r][2]);
+        }
+        return;
+    }
     atomicAdd(gb + 3 * i0, gx0); atomicAdd(gb + 3 * i0 + 1, gy0); atomicAdd(gb + 3 * i0 + 2, dz0);
     atomicAdd(gb + 3 * i1, gx1); atomicAdd(gb + 3 * i1 + 1, gy1); atomicAdd(gb + 3 * i1 + 2, dz1);
     atomicAdd(gb + 3 * i2, gx2); atomicAdd(gb + 3 * i2 + 1, gy2); atomicAdd(gb + 3 * i2 + 2, dz2);
 }
 
 template <int K>
-void launch_raster_k(const float4 *rec, int B, int F, int S, float blur, int clip, int cull, int persp, int32_t *p2f,
-                     float *zbuf, float *bary, float *dists, hipStream_t s) {
+void launch_raster_k(const float4 *rec, int B, int F, int S, float blur, int clip, int cull, int persp, int rpf, int32_t *p2f,
+                     float *zbuf, float *bary, float *dists, int32_t *slots, hipStream_t s) {
     const int tiles = st3d::cdiv(S, TILE);
-    raster_k_kernel<K><<<dim3(tiles, tiles, B), 256, 0, s>>>(rec, F, S, blur, clip, cull, persp, p2f, zbuf, bary, dists);
+    raster_k_kernel<K><<<dim3(tiles, tiles, B), 256, 0, s>>>(rec, F * rpf, S, blur, clip, cull, persp, rpf, p2f, zbuf, bary, dists,
+                                                             slots);
 }
 
 }  // namespace
 
+extern "C" size_t st3d_clip_records_bytes(int B, int F) { return (size_t)B * (size_t)F * 2 * 3 * sizeof(float4); }
+
+extern "C" int st3d_face_setup_clip(const float *verts_ndc, const int32_t *faces, int B, int V, int F, float z_clip,
+                                    int perspective_correct, void *face_records, size_t records_bytes, st3d_stream_t stream) {
+    ST3D_CHECK_ARG(verts_ndc && faces && face_records);
+    ST3D_CHECK_ARG(B > 0 && V > 0 && F > 0 && z_clip > 0.f && records_bytes >= st3d_clip_records_bytes(B, F));
+    ST3D_CHECK_ARG(((uintptr_t)face_records & 15) == 0);
+    face_setup_clip_kernel<<<st3d::cdiv((long)B * F, 256), 256, 0, st3d::as_stream(stream)>>>(
+        verts_ndc, faces, B, V, F, z_clip, perspective_correct, reinterpret_cast<float4 *>(face_records));
+    ST3D_LAUNCH_CHECK();
+    return ST3D_OK;
+}
+
 extern "C" int st3d_raster_soft_fwd(const float *face_records, int B, int F, int S, int K, float blur_radius, int clip_bary,
-                                    int cull_backfaces, int perspective_correct, int32_t *pix_to_face, float *zbuf, float *bary, float *dists, st3d_stream_t stream) {
+                                    int cull_backfaces, int perspective_correct, int records_per_face, int32_t *frag_slot,
+                                    int32_t *pix_to_face, float *zbuf, float *bary, float *dists, st3d_stream_t stream) {
     ST3D_CHECK_ARG(face_records && pix_to_face && zbuf && bary && dists);
     ST3D_CHECK_ARG(B > 0 && F > 0 && S > 0 && K >= 1 && K <= 8 && blur_radius >= 0.f);
+    ST3D_CHECK_ARG(records_per_face == 1 || records_per_face == 2);
     ST3D_CHECK_ARG(((uintptr_t)face_records & 15) == 0);
     hipStream_t s = st3d::as_stream(stream);
     const float4 *rec = reinterpret_cast<const float4 *>(face_records);
     switch (K) {
-        case 1: launch_raster_k<1>(rec, B, F, S, blur_radius, clip_bary, cull_backfaces, perspective_correct, pix_to_face, zbuf, bary, dists, s); break;
-        case 2: launch_raster_k<2>(rec, B, F, S, blur_radius, clip_bary, cull_backfaces, perspective_correct, pix_to_face, zbuf, bary, dists, s); break;
-        case 3: launch_raster_k<3>(rec, B, F, S, blur_radius, clip_bary, cull_backfaces, perspective_correct, pix_to_face, zbuf, bary, dists, s); break;
-        case 4: launch_raster_k<4>(rec, B, F, S, blur_radius, clip_bary, cull_backfaces, perspective_correct, pix_to_face, zbuf, bary, dists, s); break;
-        case 5: launch_raster_k<5>(rec, B, F, S, blur_radius, clip_bary, cull_backfaces, perspective_correct, pix_to_face, zbuf, bary, dists, s); break;
-        case 6: launch_raster_k<6>(rec, B, F, S, blur_radius, clip_bary, cull_backfaces, perspective_correct, pix_to_face, zbuf, bary, dists, s); break;
-        case 7: launch_raster_k<7>(rec, B, F, S, blur_radius, clip_bary, cull_backfaces, perspective_correct, pix_to_face, zbuf, bary, dists, s); break;
-        default: launch_raster_k<8>(rec, B, F, S, blur_radius, clip_bary, cull_backfaces, perspective_correct, pix_to_face, zbuf, bary, dists, s); break;
+        case 1: launch_raster_k<1>(rec, B, F, S, blur_radius, clip_bary, cull_backfaces, perspective_correct, records_per_face, pix_to_face, zbuf, bary, dists, frag_slot, s); break;
+        case 2: launch_raster_k<2>(rec, B, F, S, blur_radius, clip_bary, cull_backfaces, perspective_correct, records_per_face, pix_to_face, zbuf, bary, dists, frag_slot, s); break;
+        case 3: launch_raster_k<3>(rec, B, F, S, blur_radius, clip_bary, cull_backfaces, perspective_correct, records_per_face, pix_to_face, zbuf, bary, dists, frag_slot, s); break;
+        case 4: launch_raster_k<4>(rec, B, F, S, blur_radius, clip_bary, cull_backfaces, perspective_correct, records_per_face, pix_to_face, zbuf, bary, dists, frag_slot, s); break;
+        case 5: launch_raster_k<5>(rec, B, F, S, blur_radius, clip_bary, cull_backfaces, perspective_correct, records_per_face, pix_to_face, zbuf, bary, dists, frag_slot, s); break;
+        case 6: launch_raster_k<6>(rec, B, F, S, blur_radius, clip_bary, cull_backfaces, perspective_correct, records_per_face, pix_to_face, zbuf, bary, dists, frag_slot, s); break;
+        case 7: launch_raster_k<7>(rec, B, F, S, blur_radius, clip_bary, cull_backfaces, perspective_correct, records_per_face, pix_to_face, zbuf, bary, dists, frag_slot, s); break;
+        default: launch_raster_k<8>(rec, B, F, S, blur_radius, clip_bary, cull_backfaces, perspective_correct, records_per_face, pix_to_face, zbuf, bary, dists, frag_slot, s); break;
     }
     ST3D_LAUNCH_CHECK();
     return ST3D_OK;
@@ -470,15 +696,16 @@ extern "C" int st3d_shade_soft_bwd(const float *grad_rgb, const int32_t *pix_to_
 
 extern "C" int st3d_raster_soft_bwd(const float *grad_bary, const float *grad_zbuf, const float *grad_dists,
                                     const int32_t *pix_to_face, const float *verts_ndc, const int32_t *faces, int B, int V,
-                                    int F, int S, int K, int clip_bary, int perspective_correct, float *grad_verts_ndc,
-                                    st3d_stream_t stream) {
+                                    int F, int S, int K, int clip_bary, int perspective_correct, const int32_t *frag_slot,
+                                    float z_clip, float *grad_verts_ndc, st3d_stream_t stream) {
     ST3D_CHECK_ARG(pix_to_face && verts_ndc && faces && grad_verts_ndc && (grad_bary || grad_zbuf || grad_dists));
     ST3D_CHECK_ARG(B > 0 && V > 0 && F > 0 && S > 0 && K >= 1);
     hipStream_t s = st3d::as_stream(stream);
     ST3D_HIP(hipMemsetAsync(grad_verts_ndc, 0, (size_t)B * V * 3 * sizeof(float), s));
     const size_t n = (size_t)B * S * S * K;
     raster_k_bwd_kernel<<<st3d::cdiv((long)n, 256), 256, 0, s>>>(grad_bary, grad_zbuf, grad_dists, pix_to_face, verts_ndc, faces, B,
-                                                                  V, S, K, clip_bary, perspective_correct, grad_verts_ndc);
+                                                                  V, S, K, clip_bary, perspective_correct, grad_verts_ndc,
+                                                                  frag_slot, z_clip);
     ST3D_LAUNCH_CHECK();
     return ST3D_OK;
 }

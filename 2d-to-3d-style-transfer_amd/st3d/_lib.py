@@ -24,7 +24,7 @@ SIGNATURES = {
     "st3d_project_verts": (c_int, [c_f32p, c_int, c_f32p, c_f32p, c_int, c_float, c_f32p, c_stream]),
     "st3d_raster_workspace_bytes": (c_size, [c_int, c_int]),
     "st3d_raster_fwd": (c_int, [c_f32p, c_i32p, c_int, c_int, c_int, c_int, ctypes.c_void_p, c_size, c_i32p, c_f32p,
-                                c_f32p, c_f32p, c_stream]),
+                                c_f32p, c_f32p, c_float, c_i32p, c_stream]),
     "st3d_shade_fwd": (c_int, [c_i32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_int, c_int, c_int, c_int, c_int,
                                c_f32p, c_f32p, c_stream]),
     "st3d_shade_bwd": (c_int, [c_f32p, c_i32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_int, c_int, c_int, c_int,
@@ -40,14 +40,16 @@ SIGNATURES = {
     "st3d_mesh_reg": (c_int, [c_f32p, c_f32p, c_int, c_i32p, c_int, c_i32p, c_i32p, c_i32p, c_int,
                               ctypes.POINTER(c_float), c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
     "st3d_face_setup": (c_int, [c_f32p, c_i32p, c_int, c_int, c_int, ctypes.c_void_p, c_size, c_stream]),
-    "st3d_raster_soft_fwd": (c_int, [c_f32p, c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_int, c_i32p, c_f32p, c_f32p,
-                                     c_f32p, c_stream]),
+    "st3d_clip_records_bytes": (c_size, [c_int, c_int]),
+    "st3d_face_setup_clip": (c_int, [c_f32p, c_i32p, c_int, c_int, c_int, c_float, c_int, ctypes.c_void_p, c_size, c_stream]),
+    "st3d_raster_soft_fwd": (c_int, [c_f32p, c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_int, c_int, c_i32p, c_i32p,
+                                     c_f32p, c_f32p, c_f32p, c_stream]),
     "st3d_shade_soft_fwd": (c_int, [c_i32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_int, c_int, c_int, c_int, c_float,
                                     c_float, ctypes.POINTER(c_float), c_f32p, c_f32p, c_stream]),
     "st3d_shade_soft_bwd": (c_int, [c_f32p, c_i32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_int, c_int, c_int, c_int,
                                     c_float, c_float, ctypes.POINTER(c_float), c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
     "st3d_raster_soft_bwd": (c_int, [c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_i32p, c_int, c_int, c_int, c_int, c_int, c_int,
-                                     c_int, c_f32p, c_stream]),
+                                     c_int, c_i32p, c_float, c_f32p, c_stream]),
     "st3d_apply_background": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_f32p, c_stream]),
     "st3d_conv3x3_packed_floats": (c_size, [c_int, c_int]),
     "st3d_conv3x3_pack": (c_int, [c_f32p, c_int, c_int, c_f32p, c_f32p, c_stream]),

@@ -297,7 +297,9 @@ class Run:
 
     def export(self, mesh):
         """final_render/view_k.png from 12 turntable cameras + final.obj/.mtl/.png (first_approach.py:219-225)."""
+        from . import ops as _ops
         self.writer.flush()
+        _ops.check_near_plane(block=True)       # a mesh that reached the near clipping plane fails loudly (no clipping at K = 1)
         if self.main:
             u = self._utils
             final = u.finalize_mesh(mesh)

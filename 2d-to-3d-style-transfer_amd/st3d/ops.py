@@ -42,8 +42,33 @@ def project_verts(verts, R, T):
     return out
 
 
-def raster_fwd(verts_ndc, faces_i32, S):
-    """-> pix_to_face (B,S,S) int32, zbuf (B,S,S), bary (B,S,S,3), dists (B,S,S)."""
+# ---- near-plane watch of the specialised K = 1 rasteriser.  PyTorch3D clips every mesh at z_clip_value = znear / 2 before
+# rasterising; the K = 1 / blur 0 kernels do not clip (for the reference's cameras nothing comes nearer than 0.78), so they
+# raise a device flag when a rasterised face has a vertex nearer than z_clip.  The flag travels to pinned host memory
+# without blocking and is looked at when a later call finds its copy complete (or by check_near_plane(block=True)): a mesh
+# that does reach the plane fails loudly, one call late, instead of being rendered differently from PyTorch3D.
+_NEAR_PENDING = []
+NEAR_PLANE_MESSAGE = ("a rasterised face has a vertex nearer than z_clip_value (PyTorch3D clips meshes at znear / 2 = 0.5); the "
+                      "specialised K = 1 kernels do not clip -- construct RasterizationSettings(z_clip_value=0.5) to render "
+                      "through the general kernels, which do")
+
+
+def check_near_plane(block=False):
+    while _NEAR_PENDING:
+        host, ev = _NEAR_PENDING[0]
+        if block:
+            ev.synchronize()
+        elif not ev.query():
+            break
+        _NEAR_PENDING.pop(0)
+        if int(host[0]) != 0:
+            _NEAR_PENDING.clear()
+            raise RuntimeError(NEAR_PLANE_MESSAGE)
+
+
+def raster_fwd(verts_ndc, faces_i32, S, z_clip=None):
+    """-> pix_to_face (B,S,S) int32, zbuf (B,S,S), bary (B,S,S,3), dists (B,S,S).  z_clip: depth the near-plane watch
+    compares with (None = no watch)."""
     B, V, _ = verts_ndc.shape
     F = faces_i32.shape[0]
     dev = verts_ndc.device
@@ -53,8 +78,16 @@ def raster_fwd(verts_ndc, faces_i32, S):
     zbuf = torch.empty((B, S, S), dtype=F32, device=dev)
     bary = torch.empty((B, S, S, 3), dtype=F32, device=dev)
     dists = torch.empty((B, S, S), dtype=F32, device=dev)
+    flag = torch.zeros((1,), dtype=I32, device=dev) if z_clip is not None else None
     call("st3d_raster_fwd", dptr(verts_ndc, F32), dptr(faces_i32, I32), B, V, F, S, dptr(ws), ws_bytes, dptr(p2f),
-         dptr(zbuf), dptr(bary), dptr(dists), stream_ptr())
+         dptr(zbuf), dptr(bary), dptr(dists), float(z_clip or 0.0), dptr(flag), stream_ptr())
+    if flag is not None:
+        check_near_plane()
+        host = torch.empty((1,), dtype=I32, pin_memory=True)
+        host.copy_(flag, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        _NEAR_PENDING.append((host, ev))
     return p2f, zbuf, bary, dists
 
 
@@ -152,23 +185,34 @@ def mesh_reg(verts, target, topo, weights, want_grad=True):
 
 # ------------------------------------------------------------------ general soft renderer (K faces per pixel, blur)
 def raster_soft_fwd(verts_ndc, faces_i32, S, K, blur_radius=0.0, clip_bary=None, cull_backfaces=False,
-                    perspective_correct=True):
-    """-> pix_to_face (B,S,S,K) int32, zbuf, bary (B,S,S,K,3), dists; clip_bary None = PyTorch3D default (blur > 0)."""
+                    perspective_correct=True, z_clip=None):
+    """-> pix_to_face (B,S,S,K) int32, zbuf, bary (B,S,S,K,3), dists; clip_bary None = PyTorch3D default (blur > 0).
+    z_clip: near-plane clipping depth (PyTorch3D: znear / 2); then a fifth tensor, the record slot of every fragment,
+    is returned for raster_soft_bwd."""
     B, V, _ = verts_ndc.shape
     F = faces_i32.shape[0]
     dev = verts_ndc.device
     if clip_bary is None:
         clip_bary = blur_radius > 0.0
-    ws_bytes = _lib.load().st3d_raster_workspace_bytes(B, F)
-    rec = torch.empty((ws_bytes // 4,), dtype=F32, device=dev)
-    call("st3d_face_setup", dptr(verts_ndc, F32), dptr(faces_i32, I32), B, V, F, dptr(rec), ws_bytes, stream_ptr())
+    slots = None
+    if z_clip is None:
+        ws_bytes = _lib.load().st3d_raster_workspace_bytes(B, F)
+        rec = torch.empty((ws_bytes // 4,), dtype=F32, device=dev)
+        call("st3d_face_setup", dptr(verts_ndc, F32), dptr(faces_i32, I32), B, V, F, dptr(rec), ws_bytes, stream_ptr())
+    else:
+        ws_bytes = _lib.load().st3d_clip_records_bytes(B, F)
+        rec = torch.empty((ws_bytes // 4,), dtype=F32, device=dev)
+        call("st3d_face_setup_clip", dptr(verts_ndc, F32), dptr(faces_i32, I32), B, V, F, float(z_clip),
+             1 if perspective_correct else 0, dptr(rec), ws_bytes, stream_ptr())
+        slots = torch.empty((B, S, S, K), dtype=I32, device=dev)
     p2f = torch.empty((B, S, S, K), dtype=I32, device=dev)
     zbuf = torch.empty((B, S, S, K), dtype=F32, device=dev)
     bary = torch.empty((B, S, S, K, 3), dtype=F32, device=dev)
     dists = torch.empty((B, S, S, K), dtype=F32, device=dev)
     call("st3d_raster_soft_fwd", dptr(rec), B, F, S, int(K), float(blur_radius), 1 if clip_bary else 0,
-         1 if cull_backfaces else 0, 1 if perspective_correct else 0, dptr(p2f), dptr(zbuf), dptr(bary), dptr(dists), stream_ptr())
-    return p2f, zbuf, bary, dists
+         1 if cull_backfaces else 0, 1 if perspective_correct else 0, 1 if slots is None else 2, dptr(slots), dptr(p2f),
+         dptr(zbuf), dptr(bary), dptr(dists), stream_ptr())
+    return (p2f, zbuf, bary, dists) if slots is None else (p2f, zbuf, bary, dists, slots)
 
 
 def _bg3(background):
@@ -203,14 +247,14 @@ def shade_soft_bwd(grad_rgb, frag, verts_uvs, faces_uvs_i32, texture, sigma=1e-4
     return gt, ((gb, gz, gd) if want_geometry else None)
 
 
-def raster_soft_bwd(grads, p2f, verts_ndc, faces_i32, clip_bary, perspective_correct=True):
+def raster_soft_bwd(grads, p2f, verts_ndc, faces_i32, clip_bary, perspective_correct=True, slots=None, z_clip=None):
     gb, gz, gd = grads
     B, V, _ = verts_ndc.shape
     S, K = p2f.shape[1], p2f.shape[3]
     g = torch.empty((B, V, 3), dtype=F32, device=verts_ndc.device)
     call("st3d_raster_soft_bwd", dptr(gb, F32), dptr(gz, F32), dptr(gd, F32), dptr(p2f, I32), dptr(verts_ndc, F32),
-         dptr(faces_i32, I32), B, V, faces_i32.shape[0], S, K, 1 if clip_bary else 0, 1 if perspective_correct else 0, dptr(g),
-         stream_ptr())
+         dptr(faces_i32, I32), B, V, faces_i32.shape[0], S, K, 1 if clip_bary else 0, 1 if perspective_correct else 0,
+         dptr(slots, I32) if slots is not None else None, float(z_clip) if z_clip is not None else 0.0, dptr(g), stream_ptr())
     return g
 
 

@@ -223,8 +223,11 @@ class RasterizationSettings:
     accepted and ignored.  Anything but the reference's own values (first_approach.py:107) runs on the general kernels."""
     MAX_FACES_PER_PIXEL = 8
 
+    Z_CLIP_DEFAULT = 0.5        # PyTorch3D MeshRasterizer: z_clip_value None -> znear / 2 for perspective cameras (znear = 1)
+
     def __init__(self, image_size=256, blur_radius=0.0, faces_per_pixel=1, bin_size=None, max_faces_per_bin=None,
-                 perspective_correct=None, clip_barycentric_coords=None, cull_backfaces=False, **kw):
+                 perspective_correct=None, clip_barycentric_coords=None, cull_backfaces=False, z_clip_value=None,
+                 cull_to_frustum=False, **kw):
         if isinstance(image_size, (tuple, list)):
             if len(image_size) != 2 or image_size[0] != image_size[1]:
                 raise NotImplementedError("square images only")
@@ -238,11 +241,22 @@ class RasterizationSettings:
             else bool(clip_barycentric_coords)
         self.perspective_correct = True if perspective_correct is None else bool(perspective_correct)
         self.cull_backfaces = bool(cull_backfaces)
+        if cull_to_frustum:
+            raise NotImplementedError("cull_to_frustum=True is not implemented (PyTorch3D's default is False)")
+        if z_clip_value is not None and not z_clip_value > 0.0:
+            raise ValueError("z_clip_value must be positive")
+        # None: PyTorch3D's default plane.  The general kernels clip at it; the specialised K = 1 kernels only WATCH it
+        # (st3d.ops.check_near_plane) -- an explicit value sends the render to the general kernels
+        self.z_clip_value = None if z_clip_value is None else float(z_clip_value)
+
+    @property
+    def z_clip(self):
+        return self.Z_CLIP_DEFAULT if self.z_clip_value is None else self.z_clip_value
 
     @property
     def is_hard(self):
         return (self.faces_per_pixel == 1 and self.blur_radius == 0.0 and not self.clip_barycentric_coords
-                and self.perspective_correct and not self.cull_backfaces)
+                and self.perspective_correct and not self.cull_backfaces and self.z_clip_value is None)
 
 
 class BlendParams:
@@ -288,7 +302,7 @@ class _RenderFn(torch.autograd.Function):
             raise NotImplementedError("square texture maps only (the reference resizes to size x size)")
         uvs = verts_uvs.detach().to(torch.float32).reshape(-1, 2).contiguous()
         ndc = ops.project_verts(v, R, T)
-        frag = ops.raster_fwd(ndc, faces_i32, S)
+        frag = ops.raster_fwd(ndc, faces_i32, S, z_clip=RasterizationSettings.Z_CLIP_DEFAULT)
         rgb, mask = ops.shade_fwd(frag, uvs, faces_uvs_i32, tex)
         ctx.frag, ctx.uvs, ctx.fuv, ctx.tex = frag, uvs, faces_uvs_i32, tex
         ctx.tex_shape = tex_map.shape
@@ -321,14 +335,17 @@ class _SoftRenderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, verts, tex_map, faces_i32, verts_uvs, faces_uvs_i32, R, T, S, K, blur, clip, sigma, gamma, bg,
-                cull=False, persp=True):
+                cull=False, persp=True, z_clip=None):
         v = verts.detach().to(torch.float32).contiguous()
         tex = tex_map.detach().to(torch.float32).reshape(tex_map.shape[-3], tex_map.shape[-2], 3).contiguous()
         if tex.shape[0] != tex.shape[1]:
             raise NotImplementedError("square texture maps only (the reference resizes to size x size)")
         uvs = verts_uvs.detach().to(torch.float32).reshape(-1, 2).contiguous()
         ndc = ops.project_verts(v, R, T)
-        frag = ops.raster_soft_fwd(ndc, faces_i32, S, K, blur, clip, cull, persp)
+        frag = ops.raster_soft_fwd(ndc, faces_i32, S, K, blur, clip, cull, persp, z_clip)
+        ctx.slots = frag[4] if z_clip is not None else None
+        ctx.z_clip = z_clip
+        frag = frag[:4]
         rgb, alpha = ops.shade_soft_fwd(frag, uvs, faces_uvs_i32, tex, sigma, gamma, bg)
         ctx.persp = persp
         ctx.frag, ctx.uvs, ctx.fuv, ctx.tex = frag, uvs, faces_uvs_i32, tex
@@ -351,9 +368,9 @@ class _SoftRenderFn(torch.autograd.Function):
                 gtex = gt.reshape(ctx.tex_shape)
             if need_v:
                 v, ndc, faces_i32, R, T = ctx.geom
-                gndc = ops.raster_soft_bwd(geo, ctx.frag[0], ndc, faces_i32, ctx.clip, ctx.persp)
+                gndc = ops.raster_soft_bwd(geo, ctx.frag[0], ndc, faces_i32, ctx.clip, ctx.persp, ctx.slots, ctx.z_clip)
                 gverts = ops.project_verts_bwd(v, R, T, gndc).reshape(ctx.verts_shape)
-        return (gverts, gtex) + (None,) * 14
+        return (gverts, gtex) + (None,) * 15
 
 
 def uses_hard_path(raster_settings, blend_params):
@@ -380,7 +397,7 @@ def render_views(meshes, R, T, image_size, raster_settings=None, blend_params=No
     return _SoftRenderFn.apply(meshes.verts_packed(), tex.maps_padded(), meshes.faces_i32(), tex.verts_uvs_padded(),
                                tex.faces_uvs_i32(), R.to(dev), T.to(dev), int(image_size), rs.faces_per_pixel,
                                rs.blur_radius, rs.clip_barycentric_coords, bp.sigma, bp.gamma, bp.background_color,
-                               rs.cull_backfaces, rs.perspective_correct)
+                               rs.cull_backfaces, rs.perspective_correct, rs.z_clip)
 
 
 class MeshRenderer:

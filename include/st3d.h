@@ -59,7 +59,11 @@ size_t st3d_raster_workspace_bytes(int B, int F);
  * dists (signed squared edge distance), -1 filled on background. */
 int st3d_raster_fwd(const float *verts_ndc, const int32_t *faces, int B, int V, int F, int S,
                     void *workspace, size_t workspace_bytes, int32_t *pix_to_face, float *zbuf,
-                    float *bary, float *dists, st3d_stream_t stream);
+                    float *bary, float *dists,
+                    float z_clip, int32_t *near_flag /* device int, may be NULL: OR-ed with 1 when a rasterised face has a
+                    vertex nearer than z_clip -- PyTorch3D would clip it (znear / 2); this K = 1 path does not, use the
+                    general kernels (st3d_face_setup_clip) then */,
+                    st3d_stream_t stream);
 
 /* Fused TexturesUV.sample_textures + ambient shading + softmax_rgb_blend (K=1) + the
  * RGB/mask extraction of utils.py:70-72.  texture (T,T,3) HWC as maps_padded()[0]
@@ -115,9 +119,19 @@ int st3d_raster_bwd_det(const float *grad_bary, const int32_t *pix_to_face, cons
  * Fragment arrays are (B,S,S,K[,3]), depth-sorted, -1 filled. */
 int st3d_face_setup(const float *verts_ndc, const int32_t *faces, int B, int V, int F, void *face_records,
                     size_t records_bytes /* >= st3d_raster_workspace_bytes */, st3d_stream_t stream);
+/* Near-plane clipping (PyTorch3D clips against z = z_clip_value = znear / 2 for perspective cameras before rasterising):
+ * two record slots per face -- the face itself or its part in front of the plane as one or two triangles
+ * (B * 2F records, st3d_clip_records_bytes); st3d_raster_soft_fwd then runs with records_per_face = 2, reports the ORIGINAL
+ * face in pix_to_face, converts the barycentrics back to it and writes the record slot of every fragment to frag_slot
+ * (B,S,S,K), which st3d_raster_soft_bwd needs to differentiate through the clip. */
+size_t st3d_clip_records_bytes(int B, int F);
+int st3d_face_setup_clip(const float *verts_ndc, const int32_t *faces, int B, int V, int F, float z_clip,
+                         int perspective_correct, void *face_records, size_t records_bytes, st3d_stream_t stream);
 int st3d_raster_soft_fwd(const float *face_records, int B, int F, int S, int K, float blur_radius, int clip_bary,
                          int cull_backfaces /* skip faces whose NDC area is negative */,
                          int perspective_correct /* 0: screen-space barycentrics */,
+                         int records_per_face /* 1: st3d_face_setup records; 2: st3d_face_setup_clip records */,
+                         int32_t *frag_slot /* (B,S,S,K) or NULL */,
                          int32_t *pix_to_face, float *zbuf, float *bary, float *dists, st3d_stream_t stream);
 int st3d_shade_soft_fwd(const int32_t *pix_to_face, const float *bary, const float *zbuf, const float *dists,
                         const float *verts_uvs, const int32_t *faces_uvs, const float *texture, int B, int S, int T,
@@ -133,8 +147,9 @@ int st3d_shade_soft_bwd(const float *grad_rgb, const int32_t *pix_to_face, const
 /* PyTorch3D RasterizeMeshesBackward: (grad_bary, grad_zbuf, grad_dists) -> grad_verts_ndc (B,V,3), zeroed by the call */
 int st3d_raster_soft_bwd(const float *grad_bary, const float *grad_zbuf, const float *grad_dists,
                          const int32_t *pix_to_face, const float *verts_ndc, const int32_t *faces, int B, int V, int F,
-                         int S, int K, int clip_bary, int perspective_correct, float *grad_verts_ndc,
-                         st3d_stream_t stream);
+                         int S, int K, int clip_bary, int perspective_correct,
+                         const int32_t *frag_slot /* from the clipped forward, or NULL */, float z_clip,
+                         float *grad_verts_ndc, st3d_stream_t stream);
 
 /* apply_background, utils.py:19-30: out = img*mask + bg*(1-mask); bg (B,3,S,S) or, with
  * bg_batch == 1, one (3,S,S) image broadcast over the batch.  Optional grad path is the

@@ -520,3 +520,187 @@ void ref_rasterize_k2(const float *verts_ndc, const int32_t *faces, int F, int S
         }
     }
 }
+
+/* ---------------------------------------------------------------- near-plane clipping (PyTorch3D renderer/mesh/clip.py)
+ * MeshRasterizer clips every mesh against z = z_clip_value (znear / 2 for perspective cameras) before rasterising:
+ *   no vertex behind the plane (z < z_clip)  -> the face as it is
+ *   all three behind                          -> removed
+ *   ONE behind (p1)                           -> the quadrilateral p4 p2 p3 p5 as two triangles t1 = (p4, p2, p5), t2 = (p5, p2, p3)
+ *   TWO behind (p1 = the one in front)        -> the triangle (p1, p4, p5)
+ * with p2, p3 the face's other vertices in cyclic order after p1, p4 on edge p1-p2 and p5 on edge p1-p3 at depth z_clip:
+ *   w2 = (z1 - z_clip) / (z1 - z2), w3 likewise; x/y of p4 interpolated in VIEW space when perspective_correct
+ *   (x4 = ((1 - w2) x1 z1 + w2 x2 z2) / z_clip: NDC x/y are already divided by depth), linearly in NDC otherwise.
+ * The rasteriser then works on the clipped triangles; two halves of one quadrilateral never both enter a pixel's K list
+ * (the nearer-in-the-plane one, by unsigned edge distance, replaces the other), and the outputs are converted back:
+ * pix_to_face = the ORIGINAL face, bary = bary_clipped . M with M the rows of barycentric coordinates of the clipped
+ * triangle's vertices in the original face (p4 = (1 - w2) p1 + w2 p2, ...); zbuf and dists stay those of the clipped
+ * triangle.  PARITY UNPINNED (PyTorch3D absent): restated from the published algorithm; analytic pins in
+ * tests/test_oracle_soft.py.
+ *
+ * One face -> two record slots (2f, 2f + 1): tri[9] = x0 y0 z0 x1 y1 z1 x2 y2 z2, code 0 = empty, 1 = unclipped,
+ * 2 + p1 + 3 * kind with kind 0 = t1, 1 = t2 (one vertex behind), 2 = the two-behind triangle; w[2] = (w2, w3). */
+void ref_clip_face(const float v[9], float z_clip, int perspective_correct, float tri[2][9], int code[2], float w[2])
+{
+    code[0] = code[1] = 0; w[0] = w[1] = 0.f;
+    const int behind[3] = {v[2] < z_clip, v[5] < z_clip, v[8] < z_clip};
+    const int nb = behind[0] + behind[1] + behind[2];
+    if (nb == 0) { memcpy(tri[0], v, 9 * sizeof(float)); code[0] = 1; return; }
+    if (nb == 3) return;
+    int i1 = 0;                                   /* the vertex alone on its side of the plane */
+    for (int i = 0; i < 3; ++i) if (behind[i] == (nb == 1)) i1 = i;
+    const int i2 = (i1 + 1) % 3, i3 = (i1 + 2) % 3;
+    const float *p1 = v + 3 * i1, *p2 = v + 3 * i2, *p3 = v + 3 * i3;
+    const float w2 = (p1[2] - z_clip) / (p1[2] - p2[2]);
+    const float w3 = (p1[2] - z_clip) / (p1[2] - p3[2]);
+    float p4[3], p5[3];
+    if (perspective_correct) {
+        p4[0] = ((1.0f - w2) * (p1[0] * p1[2]) + w2 * (p2[0] * p2[2])) / z_clip;
+        p4[1] = ((1.0f - w2) * (p1[1] * p1[2]) + w2 * (p2[1] * p2[2])) / z_clip;
+        p5[0] = ((1.0f - w3) * (p1[0] * p1[2]) + w3 * (p3[0] * p3[2])) / z_clip;
+        p5[1] = ((1.0f - w3) * (p1[1] * p1[2]) + w3 * (p3[1] * p3[2])) / z_clip;
+    } else {
+        p4[0] = (1.0f - w2) * p1[0] + w2 * p2[0]; p4[1] = (1.0f - w2) * p1[1] + w2 * p2[1];
+        p5[0] = (1.0f - w3) * p1[0] + w3 * p3[0]; p5[1] = (1.0f - w3) * p1[1] + w3 * p3[1];
+    }
+    p4[2] = z_clip; p5[2] = z_clip;
+    w[0] = w2; w[1] = w3;
+    if (nb == 1) {
+        memcpy(tri[0], p4, 12); memcpy(tri[0] + 3, p2, 12); memcpy(tri[0] + 6, p5, 12);
+        memcpy(tri[1], p5, 12); memcpy(tri[1] + 3, p2, 12); memcpy(tri[1] + 6, p3, 12);
+        code[0] = 2 + i1; code[1] = 2 + i1 + 3;
+    } else {
+        memcpy(tri[0], p1, 12); memcpy(tri[0] + 3, p4, 12); memcpy(tri[0] + 6, p5, 12);
+        code[0] = 2 + i1 + 6;
+    }
+}
+
+/* rows of M: barycentric coordinates (in the original face) of the clipped triangle's three vertices */
+void ref_clip_conversion(int code, float w2, float w3, float M[3][3])
+{
+    memset(M, 0, 9 * sizeof(float));
+    if (code <= 1) { M[0][0] = M[1][1] = M[2][2] = 1.f; return; }
+    const int i1 = (code - 2) % 3, kind = (code - 2) / 3, i2 = (i1 + 1) % 3, i3 = (i1 + 2) % 3;
+    float b4[3] = {0, 0, 0}, b5[3] = {0, 0, 0}, b1[3] = {0, 0, 0}, b2[3] = {0, 0, 0}, b3[3] = {0, 0, 0};
+    b4[i1] = 1.0f - w2; b4[i2] = w2; b5[i1] = 1.0f - w3; b5[i3] = w3; b1[i1] = 1.f; b2[i2] = 1.f; b3[i3] = 1.f;
+    const float *rows[3];
+    if (kind == 0) { rows[0] = b4; rows[1] = b2; rows[2] = b5; }
+    else if (kind == 1) { rows[0] = b5; rows[1] = b2; rows[2] = b3; }
+    else { rows[0] = b1; rows[1] = b4; rows[2] = b5; }
+    for (int r = 0; r < 3; ++r) memcpy(M[r], rows[r], 12);
+}
+
+/* ref_rasterize_k2 + near-plane clipping at z_clip (< 0: off).  frag_slot (S,S,K) or NULL: the record slot 2 f + sub the
+ * fragment came from (the HIP backward needs it; -1 = empty). */
+void ref_rasterize_k3(const float *verts_ndc, const int32_t *faces, int F, int S, int K,
+                      float blur_radius, int clip_bary, int cull_backfaces, int perspective_correct, float z_clip,
+                      int nthreads, int32_t *pix_to_face, float *zbuf, float *bary, float *dists, int32_t *frag_slot)
+{
+    const int N = 2 * F;
+    float *tri = (float *)malloc((size_t)N * 9 * sizeof(float));
+    int *code = (int *)malloc((size_t)N * sizeof(int));
+    float *ww = (float *)malloc((size_t)N * 2 * sizeof(float));
+    for (int f = 0; f < F; ++f) {
+        float v[9], t[2][9], w[2];
+        int c[2];
+        for (int k = 0; k < 3; ++k) memcpy(v + 3 * k, verts_ndc + 3 * faces[3 * f + k], 12);
+        if (z_clip >= 0.f) ref_clip_face(v, z_clip, perspective_correct, t, c, w);
+        else { memcpy(t[0], v, 36); c[0] = 1; c[1] = 0; w[0] = w[1] = 0.f; }
+        for (int s = 0; s < 2; ++s) {
+            memcpy(tri + (size_t)(2 * f + s) * 9, t[s], 36);
+            code[2 * f + s] = c[s]; ww[2 * (2 * f + s)] = w[0]; ww[2 * (2 * f + s) + 1] = w[1];
+        }
+    }
+    const float pad = sqrtf(blur_radius);
+    (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+    for (int yi = 0; yi < S; ++yi) {
+        const float yf = pix_to_ndc(S - 1 - yi, S);
+        for (int xi = 0; xi < S; ++xi) {
+            const float xf = pix_to_ndc(S - 1 - xi, S);
+            int qf[16]; float qz[16], qd[16], qb[16][3];
+            int qn = 0;
+            for (int sl = 0; sl < N; ++sl) {
+                if (!code[sl]) continue;
+                const float *t = tri + (size_t)sl * 9;
+                const float x0 = t[0], y0 = t[1], z0 = t[2], x1 = t[3], y1 = t[4], z1 = t[5], x2 = t[6], y2 = t[7], z2 = t[8];
+                const float xmin = fminf(x0, fminf(x1, x2)) - pad, xmax = fmaxf(x0, fmaxf(x1, x2)) + pad;
+                const float ymin = fminf(y0, fminf(y1, y2)) - pad, ymax = fmaxf(y0, fmaxf(y1, y2)) + pad;
+                if (xf > xmax || xf < xmin || yf > ymax || yf < ymin) continue;
+                if (fmaxf(z0, fmaxf(z1, z2)) < K_EPS) continue;
+                const float face_area = edge_fn(x2, y2, x0, y0, x1, y1);
+                if (face_area <= K_EPS && face_area >= -K_EPS) continue;
+                if (cull_backfaces && face_area < 0.f) continue;
+                const float area = face_area + K_EPS;
+                const float w0 = edge_fn(xf, yf, x1, y1, x2, y2) / area;
+                const float w1 = edge_fn(xf, yf, x2, y2, x0, y0) / area;
+                const float w2 = edge_fn(xf, yf, x0, y0, x1, y1) / area;
+                float b0 = w0, b1 = w1, b2 = w2;
+                if (perspective_correct) {
+                    const float t0 = w0 * z1 * z2, t1 = z0 * w1 * z2, t2 = z0 * z1 * w2;
+                    const float den = fmaxf(t0 + t1 + t2, K_EPS);
+                    b0 = t0 / den; b1 = t1 / den; b2 = t2 / den;
+                }
+                float c0 = b0, c1 = b1, c2 = b2;
+                if (clip_bary) {
+                    c0 = fminf(fmaxf(b0, 0.f), 1.f); c1 = fminf(fmaxf(b1, 0.f), 1.f); c2 = fminf(fmaxf(b2, 0.f), 1.f);
+                    const float s = fmaxf(c0 + c1 + c2, K_EPS);
+                    c0 /= s; c1 /= s; c2 /= s;
+                }
+                const float pz = c0 * z0 + c1 * z1 + c2 * z2;
+                if (pz < 0.f) continue;
+                const int inside = (b0 > 0.f) && (b1 > 0.f) && (b2 > 0.f);
+                const float d01 = point_line_dist2(xf, yf, x0, y0, x1, y1);
+                const float d12 = point_line_dist2(xf, yf, x1, y1, x2, y2);
+                const float d20 = point_line_dist2(xf, yf, x2, y2, x0, y0);
+                const float d = fminf(d01, fminf(d12, d20));
+                if (!inside && d >= blur_radius) continue;
+                const float sd = inside ? -d : d;
+                /* the other half of a split quadrilateral already in the list?  keep the one nearer in the image plane */
+                const int kind = code[sl] >= 2 ? (code[sl] - 2) / 3 : -1;
+                if (kind == 0 || kind == 1) {
+                    const int other = sl ^ 1;
+                    int at = -1;
+                    for (int j = 0; j < qn; ++j) if (qf[j] == other) at = j;
+                    if (at >= 0) {
+                        if (!(d < fabsf(qd[at]))) continue;
+                        for (int j = at; j + 1 < qn; ++j) {            /* drop it; the new one is inserted below */
+                            qf[j] = qf[j + 1]; qz[j] = qz[j + 1]; qd[j] = qd[j + 1];
+                            qb[j][0] = qb[j + 1][0]; qb[j][1] = qb[j + 1][1]; qb[j][2] = qb[j + 1][2];
+                        }
+                        --qn;
+                    }
+                }
+                int pos = qn;
+                while (pos > 0 && pz < qz[pos - 1]) --pos;
+                if (pos >= K) continue;
+                const int last = (qn < K) ? qn : K - 1;
+                for (int j = last; j > pos; --j) {
+                    qf[j] = qf[j - 1]; qz[j] = qz[j - 1]; qd[j] = qd[j - 1];
+                    qb[j][0] = qb[j - 1][0]; qb[j][1] = qb[j - 1][1]; qb[j][2] = qb[j - 1][2];
+                }
+                qf[pos] = sl; qz[pos] = pz; qd[pos] = sd; qb[pos][0] = c0; qb[pos][1] = c1; qb[pos][2] = c2;
+                if (qn < K) ++qn;
+            }
+            const size_t p = ((size_t)yi * S + xi) * K;
+            for (int k = 0; k < K; ++k) {
+                if (k < qn) {
+                    const int sl = qf[k];
+                    float M[3][3];
+                    ref_clip_conversion(code[sl], ww[2 * sl], ww[2 * sl + 1], M);
+                    pix_to_face[p + k] = sl >> 1; zbuf[p + k] = qz[k]; dists[p + k] = qd[k];
+                    for (int i = 0; i < 3; ++i)
+                        bary[3 * (p + k) + i] = code[sl] <= 1 ? qb[k][i]
+                                                              : (qb[k][0] * M[0][i] + qb[k][1] * M[1][i]) + qb[k][2] * M[2][i];
+                    if (frag_slot) frag_slot[p + k] = sl;
+                } else {
+                    pix_to_face[p + k] = -1; zbuf[p + k] = -1.f; dists[p + k] = -1.f;
+                    bary[3 * (p + k)] = -1.f; bary[3 * (p + k) + 1] = -1.f; bary[3 * (p + k) + 2] = -1.f;
+                    if (frag_slot) frag_slot[p + k] = -1;
+                }
+            }
+        }
+    }
+    free(tri); free(code); free(ww);
+}

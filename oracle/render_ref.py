@@ -56,6 +56,9 @@ def lib():
         _lib.ref_rasterize_k2.argtypes = [F32P, I32P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int,
                                           ctypes.c_int, ctypes.c_int, ctypes.c_int, I32P, F32P, F32P, F32P]
         _lib.ref_rasterize_k2.restype = None
+        _lib.ref_rasterize_k3.argtypes = [F32P, I32P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int,
+                                          ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, I32P, F32P, F32P, F32P, I32P]
+        _lib.ref_rasterize_k3.restype = None
         for f in ("ref_project_verts", "ref_rasterize", "ref_shade_fwd", "ref_shade_bwd", "ref_adam_step",
                   "ref_uv_to_bary_grad", "ref_raster_bwd", "ref_project_verts_bwd", "ref_rasterize_k"):
             getattr(_lib, f).restype = None
@@ -169,7 +172,7 @@ def rasterize(verts_ndc, faces, S, blur_radius=0.0, nthreads=1, naive=False):
 
 
 def rasterize_k(verts_ndc, faces, S, K, blur_radius=0.0, clip_bary=None, nthreads=1, cull_backfaces=False,
-                perspective_correct=True):
+                perspective_correct=True, z_clip=None, return_slots=False):
     """General soft rasteriser: (S,S,K) fragments sorted by depth.  clip_bary=None follows
     PyTorch3D's default (clip when blur_radius > 0)."""
     assert 1 <= K <= 16
@@ -181,10 +184,17 @@ def rasterize_k(verts_ndc, faces, S, K, blur_radius=0.0, clip_bary=None, nthread
     zbuf = np.empty((S, S, K), np.float32)
     bary = np.empty((S, S, K, 3), np.float32)
     dists = np.empty((S, S, K), np.float32)
-    lib().ref_rasterize_k2(_p(verts_ndc, F32P), _p(faces, I32P), faces.shape[0], S, K, blur_radius, int(bool(clip_bary)),
-                           int(bool(cull_backfaces)), int(bool(perspective_correct)), nthreads, _p(p2f, I32P), _p(zbuf, F32P),
-                           _p(bary, F32P), _p(dists, F32P))
-    return p2f, zbuf, bary, dists
+    if z_clip is None and not return_slots:
+        lib().ref_rasterize_k2(_p(verts_ndc, F32P), _p(faces, I32P), faces.shape[0], S, K, blur_radius, int(bool(clip_bary)),
+                               int(bool(cull_backfaces)), int(bool(perspective_correct)), nthreads, _p(p2f, I32P), _p(zbuf, F32P),
+                               _p(bary, F32P), _p(dists, F32P))
+        return p2f, zbuf, bary, dists
+    # near-plane clipping (PyTorch3D: z_clip_value = znear / 2 for perspective cameras)
+    slots = np.empty((S, S, K), np.int32)
+    lib().ref_rasterize_k3(_p(verts_ndc, F32P), _p(faces, I32P), faces.shape[0], S, K, blur_radius, int(bool(clip_bary)),
+                           int(bool(cull_backfaces)), int(bool(perspective_correct)), -1.0 if z_clip is None else float(z_clip),
+                           nthreads, _p(p2f, I32P), _p(zbuf, F32P), _p(bary, F32P), _p(dists, F32P), _p(slots, I32P))
+    return (p2f, zbuf, bary, dists, slots) if return_slots else (p2f, zbuf, bary, dists)
 
 
 def shade_fwd(frag, verts_uvs, faces_uvs, texture):

@@ -113,3 +113,74 @@ def soft_render(verts, R, T, faces, p2f, verts_uvs, faces_uvs, tex, S, clip_bary
     colors = sample_texture(bary, p2f, verts_uvs, faces_uvs, tex)
     rgb, alpha = softmax_rgb_blend(colors, pz, sd, mask, sigma, gamma, background)
     return rgb.permute(2, 0, 1), alpha
+
+
+# ---------------------------------------------------------------------------------------------- near-plane clipping
+def clip_face(v, z_clip, perspective_correct=True):
+    """torch restatement of oracle/raster_ref.c:ref_clip_face for ONE face: v (3,3) rows (x_ndc, y_ndc, z_view) ->
+    list of (sub-triangle (3,3), M (3,3)) with M the rows of barycentric coordinates of its vertices in the original face.
+    Differentiable in v (the HIP backward through clipped faces is checked against autograd of this)."""
+    behind = [bool(v[i, 2] < z_clip) for i in range(3)]
+    nb = sum(behind)
+    eye = torch.eye(3, dtype=v.dtype)
+    if nb == 0:
+        return [(v, eye)]
+    if nb == 3:
+        return []
+    i1 = [i for i in range(3) if behind[i] == (nb == 1)][0]
+    i2, i3 = (i1 + 1) % 3, (i1 + 2) % 3
+    p1, p2, p3 = v[i1], v[i2], v[i3]
+    w2 = (p1[2] - z_clip) / (p1[2] - p2[2])
+    w3 = (p1[2] - z_clip) / (p1[2] - p3[2])
+    zc = torch.as_tensor(z_clip, dtype=v.dtype)
+
+    def cut(pa, pb, w):
+        if perspective_correct:
+            xy = ((1 - w) * pa[:2] * pa[2] + w * pb[:2] * pb[2]) / zc
+        else:
+            xy = (1 - w) * pa[:2] + w * pb[:2]
+        return torch.cat([xy, zc.reshape(1)])
+    p4, p5 = cut(p1, p2, w2), cut(p1, p3, w3)
+    b1, b2, b3 = eye[i1], eye[i2], eye[i3]
+    b4 = (1 - w2) * b1 + w2 * b2
+    b5 = (1 - w3) * b1 + w3 * b3
+    if nb == 1:
+        return [(torch.stack([p4, p2, p5]), torch.stack([b4, b2, b5])), (torch.stack([p5, p2, p3]), torch.stack([b5, b2, b3]))]
+    return [(torch.stack([p1, p4, p5]), torch.stack([b1, b4, b5]))]
+
+
+def clipped_geometry(ndc, faces, slots, S, clip_bary, perspective_correct, z_clip):
+    """Differentiable fragment quantities for a FIXED fragment -> record-slot assignment (slots (S,S,K) from the C oracle or
+    the HIP kernel, slot = 2 * face + sub): bary in the ORIGINAL face, zbuf and signed distance of the clipped triangle."""
+    K = slots.shape[-1]
+    bary = torch.zeros(S, S, K, 3, dtype=ndc.dtype)
+    pz = torch.zeros(S, S, K, dtype=ndc.dtype)
+    sd = torch.zeros(S, S, K, dtype=ndc.dtype)
+    mask = slots >= 0
+    cache = {}
+    for yi, xi, k in torch.nonzero(mask).tolist():
+        sl = int(slots[yi, xi, k])
+        if sl not in cache:
+            subs = clip_face(ndc[faces[sl >> 1]], z_clip, perspective_correct) if z_clip is not None else [(ndc[faces[sl >> 1]], torch.eye(3, dtype=ndc.dtype))]
+            cache[sl] = subs[sl & 1]
+        tri, M = cache[sl]
+        px = torch.tensor(1.0 - (2.0 * xi + 1.0) / S, dtype=ndc.dtype)
+        py = torch.tensor(1.0 - (2.0 * yi + 1.0) / S, dtype=ndc.dtype)
+        (x0, y0, z0), (x1, y1, z1), (x2, y2, z2) = tri[0], tri[1], tri[2]
+        area = _edge(x2, y2, x0, y0, x1, y1) + K_EPS
+        w = torch.stack([_edge(px, py, x1, y1, x2, y2), _edge(px, py, x2, y2, x0, y0), _edge(px, py, x0, y0, x1, y1)]) / area
+        if perspective_correct:
+            t = torch.stack([w[0] * z1 * z2, z0 * w[1] * z2, z0 * z1 * w[2]])
+            b = t / t.sum().clamp_min(K_EPS)
+        else:
+            b = w
+        inside = bool((b > 0).all())
+        c = b
+        if clip_bary:
+            c = b.clamp(0, 1)
+            c = c / c.sum().clamp_min(K_EPS)
+        pz[yi, xi, k] = c[0] * z0 + c[1] * z1 + c[2] * z2
+        bary[yi, xi, k] = c @ M
+        d = torch.minimum(torch.minimum(_pld2(px, py, x0, y0, x1, y1), _pld2(px, py, x1, y1, x2, y2)), _pld2(px, py, x2, y2, x0, y0))
+        sd[yi, xi, k] = -d if inside else d
+    return bary, pz, sd, mask

@@ -521,6 +521,116 @@ def test_soft_raster_cull_backfaces_and_perspective_correct_flags(dev, ops, cow,
             assert rel <= 5e-5, rel
 
 
+def _near_scenes(cow):
+    """(name, ndc (V,3), faces): the analytic straddling triangles of tests/test_oracle_soft.py and the cow seen from
+    INSIDE its bounding sphere (camera 0.75 from the look-at point: hundreds of faces cross z = 0.5 or lie behind it)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_oracle_soft import _straddling_scene
+    from oracle import render_ref as rr
+    out = [("one behind", *_straddling_scene(1)), ("two behind", *_straddling_scene(2))]
+    R, T = rr.look_at_view_transform(0.75, [10.0], [35.0], at=(0, 0.10, 0.25))
+    out.append(("cow from inside", rr.project_verts(cow["verts"], R[0], T[0]), cow["faces"]))
+    return out
+
+
+@pytest.mark.parametrize("K,blur,persp", [(1, 0.0, True), (3, 2e-3, True), (2, 0.0, False)])
+def test_soft_raster_near_plane_clipping_matches_oracle(dev, ops, cow, K, blur, persp):
+    """z_clip (PyTorch3D clips meshes at znear / 2 before rasterising): clipped coverage, ORIGINAL face indices, converted
+    barycentrics, depth, distances and the fragments' record slots bit-exact against oracle/raster_ref.c:ref_rasterize_k3."""
+    from oracle import render_ref as rr
+    S = 80
+    for name, ndc_np, faces_np in _near_scenes(cow):
+        ndc = torch.from_numpy(ndc_np)[None].to(dev)
+        faces = torch.from_numpy(faces_np).to(dev)
+        got = ops.raster_soft_fwd(ndc, faces, S, K, blur, blur > 0, perspective_correct=persp, z_clip=0.5)
+        ref = rr.rasterize_k(ndc_np, faces_np, S, K, blur, blur > 0, nthreads=8, perspective_correct=persp, z_clip=0.5,
+                             return_slots=True)
+        assert len(got) == 5
+        for g, r in zip(got, ref):
+            np.testing.assert_array_equal(g[0].cpu().numpy(), r, err_msg=name)
+        slots = ref[4]
+        if name != "cow from inside":
+            assert ((slots >= 0) & (slots & 1 == 1)).any() == (name == "one behind")
+        else:
+            unclipped = rr.rasterize_k(ndc_np, faces_np, S, K, blur, blur > 0, nthreads=8, perspective_correct=persp)
+            assert (unclipped[0] != ref[0]).mean() > 0.02            # the plane really cuts this view
+            assert ((slots >= 0) & (slots & 1 == 1)).sum() > 20       # second halves of split quadrilaterals are hit
+
+
+def test_soft_raster_backward_through_clipped_faces_matches_fp64_autograd(dev, ops, cow):
+    """d loss / d projected vertices through fragments that live on clipped sub-triangles (the cut points and the
+    barycentric conversion depend on the vertices) against torch autograd of oracle/soft_ref.py:clipped_geometry."""
+    from oracle import soft_ref as SR
+    S = 40
+    rng = np.random.default_rng(0)
+    for name, ndc_np, faces_np in _near_scenes(cow)[:2]:
+        for persp, K, blur in ((True, 1, 0.0), (False, 1, 0.0), (True, 2, 3e-3)):
+            clip = blur > 0
+            ndc = torch.from_numpy(ndc_np)[None].to(dev)
+            faces = torch.from_numpy(faces_np).to(dev)
+            p2f, zbuf, bary, dists, slots = ops.raster_soft_fwd(ndc, faces, S, K, blur, clip, perspective_correct=persp, z_clip=0.5)
+            assert (slots >= 0).sum() > 15
+            gb = torch.from_numpy(rng.standard_normal((1, S, S, K, 3)).astype(np.float32)).to(dev)
+            gz = torch.from_numpy(rng.standard_normal((1, S, S, K)).astype(np.float32)).to(dev)
+            gd = torch.from_numpy(rng.standard_normal((1, S, S, K)).astype(np.float32)).to(dev)
+            g = ops.raster_soft_bwd((gb, gz, gd), p2f, ndc, faces, clip, perspective_correct=persp, slots=slots, z_clip=0.5)
+            nd = torch.from_numpy(ndc_np).double().requires_grad_(True)
+            b64, z64, d64, m64 = SR.clipped_geometry(nd, torch.from_numpy(faces_np).long(), slots[0].cpu().long(), S, clip, persp, 0.5)
+            np.testing.assert_allclose(b64.detach().numpy()[m64.numpy()], bary[0].cpu().numpy()[m64.numpy()], atol=5e-6)
+            md = m64.double()
+            ((b64 * gb[0].cpu().double() * md.unsqueeze(-1)).sum() + (z64 * gz[0].cpu().double() * md).sum()
+             + (d64 * gd[0].cpu().double() * md).sum()).backward()
+            rel = float((g[0].cpu().double() - nd.grad).norm() / nd.grad.norm())
+            assert rel <= 1e-4, (name, persp, K, rel)
+
+
+def test_renderer_near_plane_policy(dev, cow):
+    """PyTorch3D clips at z_clip_value = znear / 2.  Through MeshRenderer: an explicit z_clip_value renders on the general
+    kernels WITH clipping (pixels against the oracle's clipped fragments, gradients flow); the specialised K = 1 path does
+    not clip and must say so -- a render whose mesh reaches the plane raises at the next check instead of silently
+    differing; the reference's own views (nothing nearer than 0.78) never trip the watch."""
+    import utils as U
+    from oracle import render_ref as rr
+    from st3d import ops as O
+    from st3d.render import FoVPerspectiveCameras, MeshRasterizer, MeshRenderer, RasterizationSettings, SoftPhongShader
+    U.device = dev
+    S = 64
+    rng = np.random.default_rng(2)
+    tex_np = rng.random((32, 32, 3), dtype=np.float32)
+    tex = torch.from_numpy(tex_np)[None].to(dev).requires_grad_(True)
+    verts = torch.from_numpy(cow["verts"]).to(dev).requires_grad_(True)
+    mesh = U.build_mesh(torch.from_numpy(cow["verts_uvs"])[None].to(dev), torch.from_numpy(cow["faces_uvs"].astype(np.int64))[None].to(dev),
+                        tex, verts, torch.from_numpy(cow["faces"].astype(np.int64)).to(dev))
+    Rn, Tn = rr.look_at_view_transform(0.75, [10.0], [35.0], at=(0, 0.10, 0.25))          # camera inside the cow's bounding sphere
+    near = FoVPerspectiveCameras(R=torch.from_numpy(Rn), T=torch.from_numpy(Tn), device=dev)
+    Rf, Tf = _cams(1, seed=1)
+    far = FoVPerspectiveCameras(R=torch.from_numpy(Rf), T=torch.from_numpy(Tf), device=dev)
+    clipping = MeshRenderer(MeshRasterizer(None, RasterizationSettings(image_size=S, z_clip_value=0.5)), SoftPhongShader())
+    plain = MeshRenderer(MeshRasterizer(None, RasterizationSettings(image_size=S)), SoftPhongShader())
+    assert plain.is_hard and not clipping.is_hard
+    O.check_near_plane(block=True)
+    rgb, cov = clipping.render(mesh, near)
+    frag = rr.rasterize_k(rr.project_verts(cow["verts"], Rn[0], Tn[0]), cow["faces"], S, 1, 0.0, nthreads=8, z_clip=0.5)
+    np.testing.assert_array_equal((cov[0, 0] > 0).cpu().numpy(), frag[0][..., 0] >= 0)
+    ref_rgb, _ = rr.shade_fwd(tuple(a[..., 0] if a.ndim == 3 else a[..., 0, :] for a in frag), cow["verts_uvs"], cow["faces_uvs"], tex_np)
+    np.testing.assert_allclose(rgb[0].detach().cpu().numpy(), ref_rgb, atol=3e-6)
+    rgb.sum().backward()
+    assert torch.isfinite(verts.grad).all() and float(verts.grad.abs().sum()) > 0
+    # far view: both paths agree and the watch stays silent
+    with torch.no_grad():
+        a, _ = plain.render(mesh, far)
+        b, _ = clipping.render(mesh, far)
+    np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=2e-6)
+    O.check_near_plane(block=True)
+    # near view on the specialised path: loud
+    with torch.no_grad():
+        plain.render(mesh, near)
+    with pytest.raises(RuntimeError, match="z_clip_value"):
+        O.check_near_plane(block=True)
+    O.check_near_plane(block=True)                      # the failure is reported once
+
+
 def test_renderer_routes_non_default_raster_flags_to_the_general_kernels(dev, cow):
     """MeshRenderer with cull_backfaces=True or perspective_correct=False (K = 1, blur 0) leaves the specialised path; the
     culled render of the closed cow equals the default render, the uncorrected one differs and back-propagates."""

@@ -113,3 +113,75 @@ def test_perspective_correct_off_gives_screen_space_barycentrics():
     want /= want.sum()
     np.testing.assert_allclose(b1[yi, xi, 0], want, atol=1e-6)
     assert abs(z1[yi, xi, 0] - 1.0 / float((w / verts2[:, 2]).sum())) < 1e-5
+
+
+def _straddling_scene(n_behind):
+    """One big triangle through the near clipping plane z = 0.5 (PyTorch3D z_clip_value = znear / 2) seen by an identity
+    camera: `n_behind` of its vertices have depth 0.25 < 0.5 (still in front of the image plane, so the unclipped
+    rasteriser -- which knows nothing of the plane -- serves as the reference for barycentrics and depth)."""
+    s = 1.7320508
+    view = np.array([[-0.25, -0.2, 1.6], [0.3, -0.15, 1.1], [0.02, 0.12, 0.25]], np.float32)
+    if n_behind == 2:
+        view[1, 2] = 0.25
+        view[1, :2] *= 0.2
+    ndc = np.stack([s * view[:, 0] / view[:, 2], s * view[:, 1] / view[:, 2], view[:, 2]], 1).astype(np.float32)
+    return ndc, np.array([[0, 1, 2]], np.int32)
+
+
+def test_near_plane_clipping_keeps_the_part_in_front_and_the_original_barycentrics():
+    """z_clip: the face is cut at depth 0.5 into a quadrilateral (two triangles) or a smaller triangle; covered pixels are
+    exactly those of the uncut face whose interpolated depth is >= 0.5, pix_to_face names the ORIGINAL face and the
+    converted barycentrics / depth equal the uncut face's (to rounding), with and without perspective correction; a face
+    wholly behind the plane disappears."""
+    S = 96
+    for n_behind in (1, 2):
+        ndc, f = _straddling_scene(n_behind)
+        for persp in (True, False):
+            full = rr.rasterize_k(ndc, f, S, 1, 0.0, perspective_correct=persp)
+            p2f, z, b, d, slots = rr.rasterize_k(ndc, f, S, 1, 0.0, perspective_correct=persp, z_clip=0.5, return_slots=True)
+            cov_full, cov = full[0][..., 0] >= 0, p2f[..., 0] >= 0
+            assert cov.sum() > 50 and cov_full.sum() > cov.sum() + 20
+            # depth along the uncut face AS THIS MODE INTERPOLATES IT decides what is in front of the plane: the cut points
+            # are placed with view-space interpolation when perspective_correct, linearly in NDC otherwise
+            zt = full[1][..., 0]
+            want = cov_full & (zt >= 0.5)
+            border = np.abs(zt - 0.5) < 0.02
+            assert np.array_equal(cov[~border], want[~border])
+            assert set(np.unique(slots[cov])) == ({0, 1} if n_behind == 1 else {0})
+            assert np.all(p2f[cov] == 0)
+            np.testing.assert_allclose(b[cov, 0], full[2][cov, 0], atol=2e-5)
+            np.testing.assert_allclose(z[cov, 0], full[1][cov, 0], atol=2e-5)
+            assert np.all(z[cov, 0] >= 0.5 - 1e-5) and np.all(d[cov, 0] < 0)
+    ndc, f = _straddling_scene(1)
+    ndc[:, 2] = 0.3                                                     # every vertex behind the plane
+    assert (rr.rasterize_k(ndc, f, S, 1, 0.0, z_clip=0.5)[0] >= 0).sum() == 0
+    assert (rr.rasterize_k(ndc, f, S, 1, 0.0)[0] >= 0).sum() > 0
+
+
+def test_the_two_halves_of_a_clipped_quad_never_share_a_pixel():
+    """With blur the halo of t1 overlaps t2 along their shared diagonal; PyTorch3D keeps, per pixel, only the half whose
+    edge is nearer -- so a face appears at most once in a pixel's K list, as without clipping."""
+    S = 64
+    ndc, f = _straddling_scene(1)
+    p2f, z, b, d, slots = rr.rasterize_k(ndc, f, S, 3, 4e-3, z_clip=0.5, return_slots=True)
+    assert ((slots == 0).any(-1) & (slots == 1).any(-1)).sum() == 0
+    assert (slots[..., 1] >= 0).sum() == 0                              # one face, one layer
+    both = (slots[..., 0] == 0).sum() > 10 and (slots[..., 0] == 1).sum() > 10
+    assert both
+    nb = rr.rasterize_k(ndc, f, S, 3, 4e-3)                             # the unclipped face covers the clipped one's pixels
+    assert np.all(nb[0][..., 0][p2f[..., 0] >= 0] == 0)
+
+
+def test_clip_face_restatements_agree():
+    """oracle/soft_ref.py:clip_face (torch, differentiable) against the C restatement, all cases, both interpolations."""
+    for n_behind in (1, 2):
+        ndc, f = _straddling_scene(n_behind)
+        for persp in (True, False):
+            S = 48
+            p2f, z, b, d, slots = rr.rasterize_k(ndc, f, S, 1, 0.0, perspective_correct=persp, z_clip=0.5, return_slots=True)
+            bary, pz, sd, mask = SR.clipped_geometry(torch.from_numpy(ndc).double(), torch.from_numpy(f).long(),
+                                                     torch.from_numpy(slots).long(), S, False, persp, 0.5)
+            m = mask.numpy()
+            np.testing.assert_allclose(bary.numpy()[m], b[m], atol=3e-6)
+            np.testing.assert_allclose(pz.numpy()[m], z[m], atol=3e-6)
+            np.testing.assert_allclose(sd.numpy()[m], d[m], atol=1e-6)
