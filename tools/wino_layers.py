@@ -37,26 +37,16 @@ for name, Cin, Cout, d, pooled, in_pool in LAYERS:
         tf = timeit(lambda: ops.wino_fwd(x, uf, b, Cout, relu=True, pool=True, keep_full=False))
     else:
         tf = timeit(lambda: ops.wino_fwd(x, uf, b, Cout, relu=True))
-    gy = torch.randn(B, Cout, H, H, device=dev)
-    y = torch.randn(B, Cout, H, H, device=dev)
-    if in_pool or name == "conv1_2":
-        # gradient arrives at full resolution of this layer's OUTPUT, gated by this layer's activation
-        pass
+    gy = torch.randn(B, Cout, H, H, device=dev)        # gradient w.r.t. this layer's output ...
+    y = torch.randn(B, Cout, H, H, device=dev)         # ... gated by its (post-ReLU) activation
     td = timeit(lambda: ops.wino_dgrad(gy, y, ud, Cin))
-    tu = None
-    if pooled:      # the NEXT layer's dgrad fuses the unpool of this layer's pool; shape: next layer at H/2 -> time it on the next entry
-        pass
     rows.append((name, tf, gf / tf / 157.3, td, gf / td / 157.3))
     tot += tf + td
     print(f"{name:8s} fwd {tf:7.4f} ms {gf/tf/157.3:6.3f} | dgrad {td:7.4f} ms {gf/td/157.3:6.3f}", flush=True)
-# unpool-fused dgrads: conv2_1 (H=256, from pool1), conv3_1, conv4_1, conv5_1
-for name, Cin, Cout, d in (("conv2_1", 64, 128, 2), ("conv3_1", 128, 256, 4), ("conv4_1", 256, 512, 8), ("conv5_1", 512, 512, 16)):
+# input-gradients with the fused unpool: the layer BEFORE each pool (conv1_2, conv2_2, conv3_4, conv4_4) receives the
+# gradient at pooled resolution H and writes its input-gradient at 2H
+for Ci, Co, d in ((64, 64, 2), (128, 128, 4), (256, 256, 8), (512, 512, 16)):
     H = S // d
-    # here the dgrad of layer L (Cin->Cout at H) produces d/d(input of L) where input = pool output at H; the fused-unpool
-    # kernel belongs to the layer BEFORE the pool: its gradient input is the pooled-resolution gradient.  Shape: gy (B,Cprev,H,H)
-    # pooled, output at 2H.  Time the previous layer's dgrad_unpool: conv1_2 (64->64 at 2H) etc.
-    prev = {"conv2_1": (64, 64), "conv3_1": (128, 128), "conv4_1": (256, 256), "conv5_1": (512, 512)}[name]
-    Ci, Co = prev
     gp = torch.randn(B, Co, H, H, device=dev)
     pd = torch.randn(B, Co, H, H, device=dev)
     idx = torch.randint(0, 4, (B, Co, H, H), device=dev, dtype=torch.uint8)
