@@ -147,7 +147,7 @@ def time_ms(fn, reps=20, warm=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--views", type=int, default=8, help="views per GPU per step")
