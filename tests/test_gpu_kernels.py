@@ -722,3 +722,49 @@ def test_plan_falls_back_to_direct_kernels_above_the_wino_guard(dev):
         got = c12[:, :, y0:y0 + h, x0:x0 + h].cpu().double()
         assert float((got - ref).abs().max()) <= 5e-5 * float(ref.abs().max()), (y0, x0)
     del model
+
+
+def _random_soup(seed, F, with_traps=True):
+    """Random triangle soup in NDC: sizes from sub-pixel to half the screen, depths on both sides of the image plane and
+    of the near clipping plane, plus the traps a mesh file never guarantees against: zero-area faces, exact duplicates
+    (depth ties), vertices exactly on pixel centres (edge-function zeros), faces wholly off screen."""
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(-1.1, 1.1, (F, 1, 2))
+    size = 10 ** rng.uniform(-2.5, -0.2, (F, 1, 1))
+    xy = c + size * rng.standard_normal((F, 3, 2))
+    z = rng.uniform(0.3, 3.0, (F, 1)) + rng.uniform(-0.4, 0.4, (F, 3)) * (rng.random((F, 1)) < 0.5)
+    z[rng.random(F) < 0.03] *= -1.0                                   # behind the camera
+    v = np.concatenate([xy, z[..., None]], 2).astype(np.float32)
+    if with_traps:
+        v[1] = v[0]                                                   # duplicate face: equal depth everywhere
+        v[2, 2] = v[2, 0]                                             # two coincident vertices: zero area
+        v[3, :, :2] = np.float32(1 - (2 * 10 + 1) / 64)               # all three vertices on one pixel centre (S = 64)
+        v[4, 0, :2] = [np.float32(1 - (2 * 20 + 1) / 64), np.float32(1 - (2 * 30 + 1) / 64)]    # a vertex on a pixel centre
+        v[5, :, 0] += 5.0                                             # off screen
+    verts = v.reshape(-1, 3)
+    faces = np.arange(3 * F, dtype=np.int32).reshape(F, 3)
+    return verts, faces
+
+
+@pytest.mark.parametrize("seed,F,S", [(0, 300, 64), (1, 2500, 64), (2, 700, 100), (3, 50, 17)])
+def test_rasterisers_match_oracle_on_random_triangle_soups(dev, ops, seed, F, S):
+    """Bit-exact fragments against the C oracle on adversarial soups, for the specialised K = 1 kernel and for the general
+    kernel under every combination of the settings it implements (K, blur + barycentric clipping, back-face culling,
+    perspective correction, near-plane clipping)."""
+    from oracle import render_ref as rr
+    verts, faces = _random_soup(seed, F)
+    ndc = torch.from_numpy(verts)[None].to(dev)
+    fd = torch.from_numpy(faces).to(dev)
+    hard = ops.raster_fwd(ndc, fd, S)
+    ref = rr.rasterize(verts, faces, S, 0.0, 8)
+    for g, r in zip(hard, ref):
+        np.testing.assert_array_equal(g[0].cpu().numpy(), r)
+    assert (ref[0] >= 0).mean() > 0.03
+    combos = [(1, 0.0, False, True, None), (3, 0.0, True, True, None), (4, 1e-3, False, False, None), (2, 0.0, False, True, 0.5),
+              (8, 2e-3, True, True, 0.5), (3, 5e-4, False, False, 0.7)]
+    for K, blur, cull, persp, zc in combos:
+        got = ops.raster_soft_fwd(ndc, fd, S, K, blur, blur > 0, cull_backfaces=cull, perspective_correct=persp, z_clip=zc)
+        want = rr.rasterize_k(verts, faces, S, K, blur, blur > 0, nthreads=8, cull_backfaces=cull, perspective_correct=persp,
+                              z_clip=zc, return_slots=zc is not None)
+        for g, r in zip(got, want):
+            np.testing.assert_array_equal(g[0].cpu().numpy(), r, err_msg=str((K, blur, cull, persp, zc)))
