@@ -66,7 +66,6 @@ def test_midpoint_subdivision_keeps_the_rendered_surface():
 
 
 def test_synthesised_uvs_follow_the_documented_parametrisation():
-    import sys, os
     from oracle import loop_ref as LR
     from st3d import io
     tea = SC.load_asset("teapot")

@@ -3,7 +3,7 @@
 where the plan fuses it), gated input-gradient, input-gradient with fused unpool.  Run once per kernel variant:
     ST3D_WINO_VARIANT=8 python tools/wino_layers.py ; ST3D_WINO_VARIANT=4 python tools/wino_layers.py
 Prints ms and the fraction of the fp32-MFMA peak (issued flops = 16/36 of the direct count)."""
-import json, os, sys
+import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "2d-to-3d-style-transfer_amd"))
 import torch
