@@ -297,6 +297,8 @@ def main():
                 alg = issued = gram_alg_flops(module, S, Bv)
                 C, d = STYLE_TAPS[module]
                 nbytes = hw4(C, d) * (2 if module == 28 else 3)      # read F, (read +) write dF: conv5_1 stores, the rest accumulate
+            reps = max(n // nprof, 1)                       # launches of this (family, module) per step (2 with --no-hoist)
+            issued, alg, nbytes = issued * reps, alg * reps, nbytes * reps
             k["_issued"] += issued
             k["_alg"] += alg
             k["_bytes"] += nbytes
@@ -329,7 +331,7 @@ def main():
             ndc = ops.project_verts(out["verts"].detach(), my_cams.R, my_cams.T)
             frag = ops.raster_fwd(ndc, f32, S)
             gimg = torch.randn((Bv, 3, S, S), device=device)
-            st = optimizer._state_of(texture_map) if texture_map in optimizer.params else None
+            st = optimizer._state_of(texture_map) if any(q is texture_map for q in optimizer.params) else None
             hb = {
                 "raster_fwd": (time_ms(lambda: ops.raster_fwd(ndc, f32, S)), Bv * Fn * 52.0 + px * 24.0),
                 "shade_fwd": (time_ms(lambda: ops.shade_fwd(frag, vuv, fuv, tex2)), px * (24.0 + 16.0)),
@@ -354,6 +356,8 @@ def main():
         if args.no_hoist:
             f_alg_step += sum(conv_alg_flops(m, S, Bv) for m, *_ in CONVS if m <= 21)
         f_wino_alg = sum(conv_alg_flops(m, S, Bv) for m, *_ in CONVS if m != 0) * 2
+        if args.no_hoist:
+            f_wino_alg += sum(conv_alg_flops(m, S, Bv) for m, *_ in CONVS if 0 < m <= 21)
         f_issued_step = (f_wino_alg * (16.0 / 36.0) if wino else f_wino_alg + 2 * conv_alg_flops(0, S, Bv)) \
             + sum(gram_alg_flops(m, S, Bv) * (gram_fwd_issued_fraction(m) + 1.0) for m in STYLE_TAPS)
         step_s = dev_ms / args.steps * 1e-3
