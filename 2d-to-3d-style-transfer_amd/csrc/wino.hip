@@ -656,6 +656,11 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
     // read with ds_read_b64 and the image written with 16-byte stores (8 store instructions per lane instead of 16
     // dwordx2: the tail of a tile is store-issue bound).
     float *ex = smem;
+    // this thread's four biases are fetched NOW: a load issued between the stores below would have to wait for every
+    // older store to complete (vmcnt counts loads and stores in order), serialising the four output items
+    float bias4[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) bias4[it] = (a.bias && DBG != 4) ? a.bias[co0 + it * 16 + (tid >> 4)] : 0.f;
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
@@ -681,7 +686,7 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
 #pragma unroll
             for (int aa = 0; aa < 4; ++aa)
                 z[jj][aa] = *reinterpret_cast<const f32x2 *>(&ex[((jj * 4 + aa) * 64 + col) * 32 + 2 * pair]);
-        const float bsum = (a.bias && DBG != 4) ? a.bias[co] : 0.f;
+        const float bsum = bias4[it];
         // y[i][jj] per tile t: i = 0: z0 + z1 + z2, i = 1: z1 - z2 - z3 (along a)
         float y[2][2][2];      // [tile][row i][col jj]
 #pragma unroll
