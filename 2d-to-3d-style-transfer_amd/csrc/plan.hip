@@ -151,6 +151,14 @@ struct st3d_plan {
     int fam_n[ST3D_PROFILE_FAMILIES];
     std::vector<int> l_tag;        // per launch since the last read: family * 100 + VGG module index
     std::vector<float> l_ms;
+    // HIP-graph replay of the loss step (st3d_plan_graph): the launch sequence is static, so after one ordinary call it
+    // is captured once per (n, batch_denom, weights) and replayed; it works on plan-owned staging buffers because a
+    // captured kernel's pointers are baked in while the caller's tensors move
+    int use_graph;
+    hipGraphExec_t gexec;
+    hipStream_t cap_stream;
+    float *g_in, *g_grad, *g_loss;
+    struct { int n, denom, want_grad, warm; float sw, cw; } gkey;
 };
 
 namespace {
@@ -296,6 +304,7 @@ extern "C" int st3d_plan_create(st3d_plan **out, st3d_vgg *vgg, int B, int S) {
     for (int i = 0; i < 5; ++i) { p->pidx[i] = nullptr; p->style_gram[i] = p->gram[i] = p->D[i] = nullptr; }
     p->gbuf[0] = p->gbuf[1] = nullptr; p->content_target = nullptr; p->gram_ws = nullptr; p->partials = nullptr;
     p->have_content = p->have_style = false; p->style_batch = 0; p->last_n = 0; p->prof = false;
+    p->use_graph = 0; p->gexec = nullptr; p->cap_stream = nullptr; p->g_in = p->g_grad = p->g_loss = nullptr; memset(&p->gkey, 0, sizeof(p->gkey));
     memset(p->fam_ms, 0, sizeof(p->fam_ms)); memset(p->fam_n, 0, sizeof(p->fam_n));
     int rc = ST3D_OK;
     int C = 3, H = S, W = S;
@@ -330,6 +339,9 @@ extern "C" int st3d_plan_create(st3d_plan **out, st3d_vgg *vgg, int B, int S) {
     p->gram_ws_bytes = wsmax;
     if (rc == ST3D_OK) { float *t = nullptr; rc = dev_alloc(p, &t, wsmax / sizeof(float)); p->gram_ws = t; }
     if (rc == ST3D_OK) rc = dev_alloc(p, &p->partials, (size_t)st3d_reduce_partials());
+    if (rc == ST3D_OK) rc = dev_alloc(p, &p->g_in, (size_t)B * 3 * S * S);
+    if (rc == ST3D_OK) rc = dev_alloc(p, &p->g_grad, (size_t)B * 3 * S * S);
+    if (rc == ST3D_OK) rc = dev_alloc(p, &p->g_loss, (size_t)4);
     if (rc != ST3D_OK) { st3d_plan_destroy(p); return rc; }
     *out = p;
     return ST3D_OK;
@@ -350,6 +362,11 @@ extern "C" int st3d_plan_destroy(st3d_plan *p) {
     if (p->content_target) (void)hipFree(p->content_target);
     if (p->gram_ws) (void)hipFree(p->gram_ws);
     if (p->partials) (void)hipFree(p->partials);
+    if (p->g_in) (void)hipFree(p->g_in);
+    if (p->g_grad) (void)hipFree(p->g_grad);
+    if (p->g_loss) (void)hipFree(p->g_loss);
+    if (p->gexec) (void)hipGraphExecDestroy(p->gexec);
+    if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
     for (auto &e : p->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto &e : p->pool) (void)hipEventDestroy(e);
     delete p;
@@ -419,6 +436,17 @@ extern "C" int st3d_plan_set_style(st3d_plan *p, const float *style, int style_b
     return ST3D_OK;
 }
 
+static int plan_loss_enqueue(st3d_plan *p, const float *current, int n, int batch_denom, float style_weight,
+                             float content_weight, float *loss_out, float *grad_current, hipStream_t s);
+
+extern "C" int st3d_plan_graph(st3d_plan *p, int enable) {
+    ST3D_CHECK_ARG(p);
+    p->use_graph = enable ? 1 : 0;
+    if (!enable && p->gexec) { (void)hipGraphExecDestroy(p->gexec); p->gexec = nullptr; }
+    p->gkey.warm = 0;
+    return ST3D_OK;
+}
+
 extern "C" int st3d_plan_loss(st3d_plan *p, const float *current, int n, int batch_denom, float style_weight,
                               float content_weight, float *loss_out, float *grad_current, st3d_stream_t stream) {
     ST3D_CHECK_ARG(p && current && loss_out);
@@ -429,6 +457,48 @@ extern "C" int st3d_plan_loss(st3d_plan *p, const float *current, int n, int bat
     }
     ST3D_CHECK_ARG(p->style_batch == 1 || p->style_batch == n);
     hipStream_t s = st3d::as_stream(stream);
+    if (!p->use_graph || p->prof) return plan_loss_enqueue(p, current, n, batch_denom, style_weight, content_weight, loss_out, grad_current, s);
+
+    // ---- graph replay
+    const size_t img = (size_t)n * 3 * p->S * p->S;
+    const int want_grad = grad_current ? 1 : 0;
+    const bool same = p->gexec && p->gkey.n == n && p->gkey.denom == batch_denom && p->gkey.want_grad == want_grad &&
+                      p->gkey.sw == style_weight && p->gkey.cw == content_weight;
+    if (!same) {
+        if (p->gexec) { (void)hipGraphExecDestroy(p->gexec); p->gexec = nullptr; }
+        const bool warm = p->gkey.warm && p->gkey.n == n && p->gkey.denom == batch_denom && p->gkey.want_grad == want_grad &&
+                          p->gkey.sw == style_weight && p->gkey.cw == content_weight;
+        p->gkey.n = n; p->gkey.denom = batch_denom; p->gkey.want_grad = want_grad; p->gkey.sw = style_weight; p->gkey.cw = content_weight;
+        if (!warm) {            // first call with these parameters: run it plainly (loads every code object, nothing to capture yet)
+            p->gkey.warm = 1;
+            return plan_loss_enqueue(p, current, n, batch_denom, style_weight, content_weight, loss_out, grad_current, s);
+        }
+        hipGraph_t graph = nullptr;
+        // captured on a stream of the plan's own: the caller's stream is usually the (uncapturable) default stream
+        if (!p->cap_stream) ST3D_HIP(hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking));
+        ST3D_HIP(hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeThreadLocal));
+        const int rc = plan_loss_enqueue(p, p->g_in, n, batch_denom, style_weight, content_weight, p->g_loss,
+                                         want_grad ? p->g_grad : nullptr, p->cap_stream);
+        const hipError_t e = hipStreamEndCapture(p->cap_stream, &graph);
+        if (rc != ST3D_OK || e != hipSuccess || !graph) {
+            if (graph) (void)hipGraphDestroy(graph);
+            if (rc == ST3D_OK) st3d::set_error("st3d_plan_loss: stream capture failed: %s", hipGetErrorString(e));
+            return rc != ST3D_OK ? rc : ST3D_E_HIP;
+        }
+        const hipError_t ei = hipGraphInstantiate(&p->gexec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (ei != hipSuccess) { p->gexec = nullptr; st3d::set_error("st3d_plan_loss: hipGraphInstantiate: %s", hipGetErrorString(ei)); return ST3D_E_HIP; }
+    }
+    ST3D_HIP(hipMemcpyAsync(p->g_in, current, img * sizeof(float), hipMemcpyDeviceToDevice, s));
+    ST3D_HIP(hipGraphLaunch(p->gexec, s));
+    ST3D_HIP(hipMemcpyAsync(loss_out, p->g_loss, 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (grad_current) ST3D_HIP(hipMemcpyAsync(grad_current, p->g_grad, img * sizeof(float), hipMemcpyDeviceToDevice, s));
+    p->last_n = n;
+    return ST3D_OK;
+}
+
+static int plan_loss_enqueue(st3d_plan *p, const float *current, int n, int batch_denom, float style_weight,
+                             float content_weight, float *loss_out, float *grad_current, hipStream_t s) {
     ST3D_TRY(forward(p, current, n, 28, false, s));
     ST3D_HIP(hipMemsetAsync(loss_out, 0, 3 * sizeof(float), s));
 

@@ -90,6 +90,7 @@ SIGNATURES = {
     "st3d_plan_set_content_features": (c_int, [ctypes.c_void_p, c_f32p, c_int, c_stream]),
     "st3d_plan_set_style": (c_int, [ctypes.c_void_p, c_f32p, c_int, c_int, c_stream]),
     "st3d_plan_loss": (c_int, [ctypes.c_void_p, c_f32p, c_int, c_int, c_float, c_float, c_f32p, c_f32p, c_stream]),
+    "st3d_plan_graph": (c_int, [ctypes.c_void_p, c_int]),
     "st3d_plan_backward": (c_int, [ctypes.c_void_p, c_int, c_int, ctypes.POINTER(ctypes.c_void_p), c_f32p, c_stream]),
     "st3d_comm_unique_id": (c_int, [ctypes.c_char_p]),
     "st3d_comm_init": (c_int, [ctypes.POINTER(ctypes.c_void_p), c_int, c_int, ctypes.c_char_p]),

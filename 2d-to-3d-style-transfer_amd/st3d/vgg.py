@@ -145,6 +145,12 @@ class PerceptualPlan:
         self._content_ref = self._style_ref = None      # the keyed tensors themselves (see _same)
         self.generation = 0         # bumped by every call that runs a VGG forward in this plan's buffers
         self.loss_buf = torch.zeros((3,), dtype=torch.float32, device=vgg.device)
+        if os.environ.get("ST3D_GRAPH", "0") not in ("", "0"):
+            self.use_graph(True)
+
+    def use_graph(self, on=True):
+        """Replay the loss step as one HIP graph (st3d_plan_graph); off by default."""
+        call("st3d_plan_graph", self._h, 1 if on else 0)
 
     def close(self):
         if self._h:

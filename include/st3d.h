@@ -288,6 +288,10 @@ int st3d_plan_set_style(st3d_plan *plan, const float *style, int style_batch, in
  * sharded over ranks).  loss_out: device float[3] = {total, content_loss, style_loss}. */
 int st3d_plan_loss(st3d_plan *plan, const float *current, int n, int batch_denom, float style_weight,
                    float content_weight, float *loss_out, float *grad_current, st3d_stream_t stream);
+/* HIP-graph replay of st3d_plan_loss: its ~70 launches form a static sequence, so after one ordinary call it is captured
+ * (per n / batch_denom / weights) and replayed with one hipGraphLaunch; inputs and outputs pass through plan-owned staging
+ * buffers (three extra device copies per call).  Pays off where the step is launch-bound (small images). */
+int st3d_plan_graph(st3d_plan *plan, int enable);
 /* Backward of st3d_plan_forward for losses computed OUTSIDE the library on its taps (the reference's own loop body,
  * style_transfer.py:61-83, calls get_features(optimized_imgs) with grad and back-propagates through it):
  * grad_modules = host array of 37 device pointers, entry m = d loss / d (output of VGG module m) shaped like

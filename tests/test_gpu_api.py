@@ -848,3 +848,46 @@ def test_differentiable_get_features_custom_taps_match_torch_autograd(mods, vgg)
         assert abs(float(loss.detach()) - float(ref_loss.detach())) <= 1e-4 * abs(float(ref_loss.detach()))
         rel = float((xg.grad.cpu().double() - xr.grad).norm() / xr.grad.norm())
         assert rel <= 1e-4, (S, rel)
+
+
+def test_graph_replay_of_the_loss_step_is_bitwise_identical(mods, vgg):
+    """PerceptualPlan.use_graph(): after one ordinary call the static launch sequence of st3d_plan_loss is captured into a
+    HIP graph and replayed.  Same kernels in the same order: loss and gradient must be bit-identical to the plain path --
+    across steps, after the content target changed (the graph reads the plan's buffers, not the caller's), and after a
+    change of batch size / weights (re-capture)."""
+    _, L, _, dev = mods
+    S, B = 64, 2
+    g = torch.Generator().manual_seed(0)
+    imgs = [torch.rand(B, 3, S, S, generator=g).to(dev) for _ in range(4)]
+    con = [torch.rand(B, 3, S, S, generator=g).to(dev) for _ in range(2)]
+    sty = torch.rand(1, 3, S, S, generator=g).to(dev)
+    plan = vgg.plan(B, S)
+
+    def run(graph):
+        plan.use_graph(graph)
+        out = []
+        try:
+            for k, (sw, n) in enumerate(((1e6, B), (1e6, B), (1e6, B), (2e5, B), (2e5, 1), (2e5, 1))):
+                plan.set_content(con[k % 2][:n], force=True)
+                plan.set_style(sty, n, force=True)
+                loss, grad = plan.loss(imgs[k % 4][:n], sw, 1.0)
+                out.append((loss.clone(), grad.clone()))
+        finally:
+            plan.use_graph(False)
+        return out
+    plain, replay = run(False), run(True)
+    for (l0, g0), (l1, g1) in zip(plain, replay):
+        assert torch.equal(l0, l1) and torch.equal(g0, g1)
+    # through the public API too
+    x = imgs[0].clone().requires_grad_(True)
+    plan.use_graph(True)
+    try:
+        vals = []
+        for _ in range(3):
+            x.grad = None
+            loss = L.compute_perceptual_loss(x, con[0], sty.expand(B, -1, -1, -1), vgg)
+            loss.backward()
+            vals.append((loss.item(), x.grad.clone()))
+    finally:
+        plan.use_graph(False)
+    assert vals[0][0] == vals[1][0] == vals[2][0] and torch.equal(vals[0][1], vals[2][1])

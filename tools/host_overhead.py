@@ -7,8 +7,9 @@ import torch
 from st3d import vgg as V, optim as O
 dev = torch.device("cuda:0")
 model = V.Vgg19Features(V.synthetic_state(0), device=dev)
-for B, S in ((4, 256), (2, 128), (8, 512)):
+for B, S, graph in ((4, 256, 0), (4, 256, 1), (2, 128, 0), (2, 128, 1), (8, 512, 0), (8, 512, 1)):
     plan = model.plan(B, S)
+    plan.use_graph(bool(graph))
     x = torch.rand(B, 3, S, S, device=dev).requires_grad_(True)
     plan.set_content(torch.rand(B, 3, S, S, device=dev)); plan.set_style(torch.rand(1, 3, S, S, device=dev), B)
     opt = O.Adam([x], lr=0.01, reduce_grads=False)
@@ -23,4 +24,4 @@ for B, S in ((4, 256), (2, 128), (8, 512)):
     t_enq = time.perf_counter() - t0
     e1.record(); torch.cuda.synchronize()
     t_wall = time.perf_counter() - t0
-    print(f"B={B} S={S}: enqueue {t_enq/n*1e3:.3f} ms/step (host), wall {t_wall/n*1e3:.3f} ms/step, device {e0.elapsed_time(e1)/n:.3f} ms/step")
+    print(f"B={B} S={S} graph={graph}: enqueue {t_enq/n*1e3:.3f} ms/step (host), wall {t_wall/n*1e3:.3f} ms/step, device {e0.elapsed_time(e1)/n:.3f} ms/step")
