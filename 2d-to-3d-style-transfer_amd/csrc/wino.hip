@@ -520,7 +520,8 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
                 xi[i] = __builtin_amdgcn_raw_buffer_load_b16(ridx, voff[i] == kOob ? kOob : voff[i] / 4, so / 4, 0);
             } else {
                 xv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff[i], so, 0));
-                if (MODE == 1) xa[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(raux, voff[i], so, 0));
+                if (MODE == 1 && DBG != 6) xa[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(raux, voff[i], so, 0));
+                if (MODE == 1 && DBG == 6) xa[i] = xv[i];      // diagnostic: no second load stream
             }
         }
     };
@@ -794,6 +795,7 @@ int launch_wino4(WinoArgs a, hipStream_t s) {
 #ifdef ST3D_WINO_DEBUG
     static const int dbgmode = [] { const char *e = getenv("ST3D_WINO_DBGMODE"); return e ? atoi(e) : 0; }();
     if (dbgmode == 1 && MODE == 0) { wino4_kernel<0, 0, 1><<<(unsigned)blocks, NT4, 0, s>>>(a); return ST3D_OK; }
+    if (dbgmode == 6 && MODE == 1) { wino4_kernel<1, 0, 6><<<(unsigned)blocks, NT4, 0, s>>>(a); return ST3D_OK; }
     if ((dbgmode == 3 || dbgmode == 4) && MODE == 0) {
         if (dbgmode == 3) { if (a.yp) wino4_kernel<0, 1, 3><<<(unsigned)blocks, NT4, 0, s>>>(a); else wino4_kernel<0, 0, 3><<<(unsigned)blocks, NT4, 0, s>>>(a); }
         else { if (a.yp) wino4_kernel<0, 1, 4><<<(unsigned)blocks, NT4, 0, s>>>(a); else wino4_kernel<0, 0, 4><<<(unsigned)blocks, NT4, 0, s>>>(a); }
