@@ -30,6 +30,7 @@ SOURCES = {
     "conv.hip": ["-fno-slp-vectorize"],   # the VALU conv1_1 kernels: SLP-packed v_pk_fma needs register-pair shuffles
     "wino.hip": ["-fno-slp-vectorize"],   # SLP-packed f32 (v_pk_*) needs register shuffles that cost matrix-pipe time
     "gram.hip": [],
+    "tap0.hip": [],
     "loss.hip": ["-ffp-contract=off"],
     "mesh.hip": [],
     "plan.hip": [],

@@ -70,6 +70,7 @@ struct st3d_vgg {
     float *bias[16];
     bool set[16];
     bool use_wino;     // ST3D_CONV=direct forces the direct kernels (A/B runs)
+    bool fuse_tap0;    // ST3D_TAP0_FUSED=0: relu1_1 Gram backward and conv1_1 input gradient as separate launches (A/B runs)
 };
 
 extern "C" int st3d_vgg_create(st3d_vgg **out) {
@@ -78,6 +79,8 @@ extern "C" int st3d_vgg_create(st3d_vgg **out) {
     memset(v, 0, sizeof(*v));
     const char *mode = getenv("ST3D_CONV");
     v->use_wino = !(mode && strcmp(mode, "direct") == 0);
+    const char *t0 = getenv("ST3D_TAP0_FUSED");
+    v->fuse_tap0 = !(t0 && t0[0] == '0');
     for (int i = 0; i < 16; ++i) {
         const size_t n = st3d_conv3x3_packed_floats(kConvCout[i], kConvCin[i]);
         bool ok = hipMalloc(&v->wf[i], n * sizeof(float)) == hipSuccess && hipMalloc(&v->wd[i], n * sizeof(float)) == hipSuccess &&
@@ -543,6 +546,15 @@ static int plan_loss_enqueue(st3d_plan *p, const float *current, int n, int batc
         int st = -1;
         for (int i = 0; i < 5; ++i)
             if (kStyleTap[i] == m) st = i;
+        if (cs == 0 && (st >= 0 || have_g) && p->vgg->fuse_tap0 && C == 64 && st3d_conv1_bwd_supported(H, W) &&
+            p->gbuf_floats >= (size_t)n * 27 * H * W) {
+            // relu1_1: style gradient + ReLU gate + conv1_1 input gradient in one pass over g and F (tap0.hip); the 27 tap
+            // planes go through the idle gradient buffer
+            Scope sc(p, F_CONVX_DGRAD, s, m);
+            ST3D_TRY(st3d_conv1_bwd(have_g ? g : nullptr, p->act[m], st >= 0 ? p->D[st] : nullptr, st >= 0 ? style_coef[st] : 0.f,
+                                    p->vgg->wd[0], gn, p->gbuf_floats * sizeof(float), grad_current, n, H, W, s));
+            break;
+        }
         if (st >= 0) {
             Scope sc(p, F_GRAM_BWD, s, m);
             ST3D_TRY(st3d_gram_bwd(p->D[st], p->act[m], n, C, H * W, style_coef[st], have_g ? 1 : 0, g, s));

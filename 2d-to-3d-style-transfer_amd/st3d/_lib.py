@@ -57,6 +57,10 @@ SIGNATURES = {
     "st3d_conv3x3_dgrad": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_stream]),
     "st3d_conv3x3_dgrad_unpool": (c_int, [c_f32p, c_u8p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int,
                                           c_stream]),
+    "st3d_conv1_bwd_supported": (c_int, [c_int, c_int]),
+    "st3d_conv1_bwd_workspace_bytes": (c_size, [c_int, c_int, c_int]),
+    "st3d_conv1_bwd": (c_int, [c_f32p, c_f32p, c_f32p, c_float, c_f32p, ctypes.c_void_p, c_size, c_f32p, c_int, c_int, c_int,
+                               c_stream]),
     "st3d_wino_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "st3d_wino_packed_floats": (c_size, [c_int, c_int]),
     "st3d_wino_pack": (c_int, [c_f32p, c_int, c_int, c_f32p, c_f32p, c_stream]),
@@ -149,6 +153,10 @@ def dptr(t, dtype=None):
         raise St3dError("libst3d takes device tensors; got a CPU tensor (no CPU fallback)")
     if not t.is_contiguous():
         raise St3dError("libst3d takes contiguous tensors")
+    if t.device.index != torch.cuda.current_device():
+        # kernels launch on torch's CURRENT device and stream; a pointer of another GPU would fault there
+        raise St3dError(f"tensor lives on {t.device} but the current device is cuda:{torch.cuda.current_device()}: "
+                        "call torch.cuda.set_device(...) (or use `with torch.cuda.device(...)`) first")
     if dtype is not None and t.dtype != dtype:
         raise St3dError(f"expected {dtype}, got {t.dtype}")
     return ctypes.c_void_p(t.data_ptr())

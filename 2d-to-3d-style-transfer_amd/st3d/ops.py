@@ -295,6 +295,17 @@ def conv3x3_dgrad(gy, act, wd, Cin):
     return gx
 
 
+def conv1_bwd(gy, act, D, coef, wd):
+    """gx (N,3,H,W) = conv1_1^T(gate(gy + coef * D act)) in one pass (st3d_conv1_bwd); gy or D may be None."""
+    N, C, H, W = act.shape
+    nb = _lib.load().st3d_conv1_bwd_workspace_bytes(N, H, W)
+    ws = torch.empty((nb // 4,), dtype=F32, device=act.device)
+    gx = torch.empty((N, 3, H, W), dtype=F32, device=act.device)
+    call("st3d_conv1_bwd", dptr(gy, F32), dptr(act, F32), dptr(D, F32), float(coef), dptr(wd, F32), dptr(ws), nb, dptr(gx),
+         N, H, W, stream_ptr())
+    return gx
+
+
 def conv3x3_dgrad_unpool(gy_pooled, pool_idx, pooled, wd, Cin):
     N, Cout, Hp, Wp = gy_pooled.shape
     H, W = 2 * Hp, 2 * Wp

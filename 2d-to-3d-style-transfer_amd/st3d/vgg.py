@@ -88,7 +88,7 @@ class Vgg19Features:
         h = ctypes.c_void_p()
         call("st3d_vgg_create", ctypes.byref(h))
         self._h = h
-        self._plans = {}
+        self._plans = OrderedDict()     # (B, S) -> PerceptualPlan, least recently used first
         self.load_state_dict(state if state is not None else synthetic_state(0))
 
     def load_state_dict(self, state):
@@ -116,11 +116,31 @@ class Vgg19Features:
     def eval(self):
         return self
 
+    MAX_PLANS = int(os.environ.get("ST3D_MAX_PLANS", "4"))
+
     def plan(self, B, S):
+        """The (cached) workspace for batch B at SxS.  A plan holds every activation of its shape (9 GB for 8 views at
+        512^2, 72 GB for 16 at 1024^2), so at most MAX_PLANS shapes stay resident, least recently used first out; a
+        plan that does not fit is retried once after the others are released.  An evicted shape is rebuilt on its next
+        use (targets are re-derived from the tensors the caller passes, see set_content / set_style)."""
         key = (int(B), int(S))
-        if key not in self._plans:
-            self._plans[key] = PerceptualPlan(self, *key)
-        return self._plans[key]
+        p = self._plans.get(key)
+        if p is not None:
+            self._plans.move_to_end(key)
+            return p
+        while len(self._plans) >= max(self.MAX_PLANS, 1):
+            self._plans.popitem(last=False)[1].close()
+        try:
+            p = PerceptualPlan(self, *key)
+        except _lib.St3dError:
+            if not self._plans:
+                raise
+            while self._plans:
+                self._plans.popitem(last=False)[1].close()
+            torch.cuda.empty_cache()
+            p = PerceptualPlan(self, *key)
+        self._plans[key] = p
+        return p
 
     def __del__(self):
         try:

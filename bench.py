@@ -283,6 +283,12 @@ def main():
             if fam in ("conv_fwd", "conv_dgrad"):
                 alg = conv_alg_flops(module, S, Bv)
                 issued = alg * (16.0 / 36.0)
+            elif fam == "convx_dgrad" and module == 0 and ("gram_bwd", 0) not in agg:
+                # csrc/tap0.hip: relu1_1 style gradient + gate + conv1_1 input gradient in one pass, both products on the
+                # matrix pipe (64x64 and 32(27)x64 per pixel); algorithmic bytes: read gradient + activation, write 3 channels
+                alg = conv_alg_flops(0, S, Bv) + gram_alg_flops(0, S, Bv)
+                issued = gram_alg_flops(0, S, Bv) + 2.0 * 32 * 64 * S * S * Bv
+                nbytes = hw4(64 + 64 + 3, 1)
             elif fam in ("convx_fwd", "convx_dgrad") and module == 0:
                 alg = conv_alg_flops(0, S, Bv)
                 # conv1_1 on the vector ALU: HBM-bound.  fwd reads 3 + writes 64 channels; dgrad reads the gradient and the
@@ -360,6 +366,8 @@ def main():
             f_wino_alg += sum(conv_alg_flops(m, S, Bv) for m, *_ in CONVS if 0 < m <= 21)
         f_issued_step = (f_wino_alg * (16.0 / 36.0) if wino else f_wino_alg + 2 * conv_alg_flops(0, S, Bv)) \
             + sum(gram_alg_flops(m, S, Bv) * (gram_fwd_issued_fraction(m) + 1.0) for m in STYLE_TAPS)
+        if os.environ.get("ST3D_TAP0_FUSED") != "0":
+            f_issued_step += 2.0 * 32 * 64 * S * S * Bv        # conv1_1's input gradient as an MFMA product (csrc/tap0.hip)
         step_s = dev_ms / args.steps * 1e-3
         std_cfg = S == 512 and Bv == 8 and not args.no_hoist and wino and args.mesh == "cow" and args.target == "texture"
         traffic, tpath = {}, ""

@@ -175,6 +175,15 @@ int st3d_conv3x3_fwd(const float *x, const float *w_fwd_packed, const float *bia
  * act (same shape, the saved post-ReLU output) gates it (act>0) when non-NULL. */
 int st3d_conv3x3_dgrad(const float *gy, const float *act, const float *w_dgrad_packed, float *gx,
                        int N, int Cin, int Cout, int H, int W, st3d_stream_t stream);
+/* The bottom of the VGG backward fused (csrc/tap0.hip): gx (N,3,H,W) = conv1_1^T(gate(gy + coef * D act)) where act
+ * (N,64,H,W) is the saved relu1_1 output (gate: act > 0), gy (N,64,H,W) the gradient arriving from conv1_2 (NULL = none)
+ * and D (N,64,64) the style-loss difference Gram of the relu1_1 tap (NULL = no tap) -- what st3d_gram_bwd(accumulate)
+ * followed by st3d_conv3x3_dgrad compute (autograd of losses.py:36-39 + second_approach.py:188), in one pass over gy and
+ * act.  w_dgrad_packed: conv1_1's dgrad pack of st3d_conv3x3_pack.  workspace: st3d_conv1_bwd_workspace_bytes. */
+int st3d_conv1_bwd_supported(int H, int W);
+size_t st3d_conv1_bwd_workspace_bytes(int N, int H, int W);
+int st3d_conv1_bwd(const float *gy, const float *act, const float *D, float coef, const float *w_dgrad_packed,
+                   void *workspace, size_t workspace_bytes, float *gx, int N, int H, int W, st3d_stream_t stream);
 /* As above, but gy is given at POOLED resolution (N,Cout,H/2,W/2) together with the pool's
  * argmax (uint8 0..3 = dy*2+dx) and pooled values: fuses max-unpool + ReLU gate into the load. */
 int st3d_conv3x3_dgrad_unpool(const float *gy_pooled, const uint8_t *pool_idx, const float *pooled,

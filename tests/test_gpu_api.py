@@ -891,3 +891,23 @@ def test_graph_replay_of_the_loss_step_is_bitwise_identical(mods, vgg):
     finally:
         plan.use_graph(False)
     assert vals[0][0] == vals[1][0] == vals[2][0] and torch.equal(vals[0][1], vals[2][1])
+
+
+def test_plan_cache_is_bounded_and_a_foreign_device_pointer_is_refused(mods, monkeypatch):
+    """Vgg19Features.plan keeps at most MAX_PLANS workspaces (least recently used first out); an evicted shape is rebuilt
+    with the same results.  st3d._lib.dptr refuses a tensor that does not live on torch's current device (the kernels
+    launch there)."""
+    _, L, U, dev = mods
+    from st3d import _lib
+    v = U.get_vgg(seed=0)
+    monkeypatch.setattr(type(v), "MAX_PLANS", 2)
+    g = torch.Generator().manual_seed(0)
+    x = {S: torch.rand(1, 3, S, S, generator=g).to(dev) for S in (32, 48, 64)}
+    first = {S: L.compute_perceptual_loss(x[S], x[S].flip(-1), x[S].flip(-2), v).item() for S in (32, 48, 64)}
+    assert list(v._plans) == [(1, 48), (1, 64)]
+    v.plan(1, 48)                   # touching a shape makes it the most recent one
+    again = L.compute_perceptual_loss(x[32], x[32].flip(-1), x[32].flip(-2), v).item()      # rebuilt, (1, 64) goes
+    assert list(v._plans) == [(1, 48), (1, 32)] and again == first[32]
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 1)
+    with pytest.raises(_lib.St3dError, match="current device"):
+        _lib.dptr(x[32])

@@ -137,6 +137,49 @@ def test_conv3x3_dgrad(dev, ops, N, Cin, Cout, H, W):
     _scale_close(gx, x.grad, 2e-5, "conv dgrad")
 
 
+@pytest.mark.parametrize("N,H,W,has_g,has_d", [(2, 64, 64, True, True), (1, 40, 52, True, True), (2, 17, 22, True, True),
+                                                (1, 128, 96, True, False), (1, 32, 32, False, True), (1, 3, 6, True, True)])
+def test_conv1_bwd_fused_matches_autograd_and_the_unfused_kernels(dev, ops, N, H, W, has_g, has_d):
+    """st3d_conv1_bwd: gx = d/dx [ sum(gy * relu1_1) + coef/2 * <D, Gram(relu1_1)> ]-style gradient, i.e.
+    conv1_1^T(gate(gy + coef * D F)) -- against fp64 autograd of the same expression and against the two launches it
+    replaces (st3d_gram_bwd(accumulate) + st3d_conv3x3_dgrad).  Sizes cover tails (HW not a multiple of 64 / 256)."""
+    torch.manual_seed(H * 7 + W)
+    x = torch.randn(N, 3, H, W, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(64, 3, 3, 3) * (2.0 / 27) ** 0.5).double()
+    b = (torch.randn(64) * 0.1).double()
+    Fm = F.relu(F.conv2d(x, w, b, padding=1))
+    gy = torch.randn_like(Fm) if has_g else None
+    D = torch.randn(N, 64, 64, dtype=torch.float64) if has_d else None
+    if has_d:
+        D = 0.5 * (D + D.transpose(1, 2))
+    coef = 0.37
+    # objective whose gradient w.r.t. F is gy + coef * D F:  <gy, F> + coef/2 * sum_n tr(F^T D F)
+    Ff = Fm.reshape(N, 64, H * W)
+    obj = 0.0
+    if has_g:
+        obj = obj + (gy * Fm).sum()
+    if has_d:
+        obj = obj + 0.5 * coef * torch.einsum("ncp,ncd,ndp->", Ff, D, Ff)
+    obj.backward()
+    _, wd = ops.conv3x3_pack(w.float().to(dev))
+    act = Fm.detach().float().to(dev)
+    gyd = gy.float().to(dev) if has_g else None
+    Dd = D.float().to(dev).contiguous() if has_d else None
+    gx = ops.conv1_bwd(gyd, act, Dd, coef, wd)
+    _scale_close(gx, x.grad, 3e-5, "fused conv1_1 backward")
+    # the launches it replaces
+    if has_g and has_d:
+        gtot = ops.gram_bwd(Dd, act, coef, out=gyd.clone())
+    elif has_d:
+        gtot = ops.gram_bwd(Dd, act, coef)
+    else:
+        gtot = gyd
+    gx2 = ops.conv3x3_dgrad(gtot, act, wd, 3)
+    _scale_close(gx, gx2, 3e-5, "fused vs unfused")
+    # fixed summation order: bitwise reproducible
+    assert torch.equal(gx, ops.conv1_bwd(gyd, act, Dd, coef, wd))
+
+
 @pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 64, 64, 32, 64), (1, 128, 128, 16, 16), (1, 256, 256, 8, 40)])
 def test_conv3x3_dgrad_unpool(dev, ops, N, Cin, Cout, H, W):
     """gradient through conv -> ReLU -> MaxPool2d(2,2) in one kernel (unpool + gate fused)."""
