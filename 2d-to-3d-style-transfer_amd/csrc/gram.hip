@@ -28,6 +28,7 @@ struct GemmArgs {
     int nsplit, kper;       // K range per split
     int tiles_m, tiles_n, tri;
     float coef; int accumulate;
+    int gate;               // backward only: zero the output where B (= F, the post-ReLU activation) is <= 0
 };
 
 // load 4 consecutive elements p[0..3] along a contiguous axis, zero past `remain`
@@ -97,6 +98,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
                 acc[m][q][r] = v;
             }
 
+    unsigned gmask[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int q = 0; q < NT; ++q) gmask[m][q] = 0xffffu;
     float4 av[A4], bv[B4];
     auto load_tiles = [&](int k0) {
 #pragma unroll
@@ -151,6 +157,24 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         store_tiles();
         __syncthreads();
         if (k0 + KCH < kend) load_tiles(k0 + KCH);   // in flight during the MFMAs below
+        if (BMODE == 1 && g.gate) {
+            // the ReLU gate of the OUTPUT rows (channels m) is the sign of F[m][n]: those rows pass through LDS as the
+            // B chunk whose k range holds m (K = M = C here), so the wave picks its 16 x NT gate bits up on the way
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int kb = m0 + wm * (MT * 32) + m * 32;
+                if (kb >= k0 && kb < k0 + KCH) {
+                    const float *pg = Bs + (kb - k0 + 4 * lhi) * LB + wn * (NT * 32) + l31;
+#pragma unroll
+                    for (int q = 0; q < NT; ++q) {
+                        unsigned mk = 0;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) mk |= (pg[((r & 3) + 8 * (r >> 2)) * LB + q * 32] > 0.f ? 1u : 0u) << r;
+                        gmask[m][q] = mk;
+                    }
+                }
+            }
+        }
         const float *pa = As + lhi * LA + wm * (MT * 32) + l31;
         const float *pb = (diag ? As : Bs) + lhi * LB + wn * (NT * 32) + l31;      // (LA == LB when TM == TN)
 #pragma unroll
@@ -178,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
             for (int q = 0; q < NT; ++q) {
                 const int gn = n0 + wn * (NT * 32) + q * 32 + l31;
                 if (gn < g.N) {
-                    Cb[(size_t)gm * g.ldc + gn] = acc[m][q][r];
+                    Cb[(size_t)gm * g.ldc + gn] = (BMODE == 1 && !((gmask[m][q] >> r) & 1u)) ? 0.f : acc[m][q][r];
                 }
             }
         }
@@ -278,12 +302,27 @@ extern "C" int st3d_gram_fwd(const float *feat, int B, int C, int HW, void *work
     return ST3D_OK;
 }
 
+static int gram_bwd_launch(const float *D, const float *feat, int B, int C, int HW, float coef, int accumulate, int gate,
+                           float *gfeat, st3d_stream_t stream);
+
 extern "C" int st3d_gram_bwd(const float *D, const float *feat, int B, int C, int HW, float coef, int accumulate,
                              float *gfeat, st3d_stream_t stream) {
+    return gram_bwd_launch(D, feat, B, C, HW, coef, accumulate, 0, gfeat, stream);
+}
+
+extern "C" int st3d_gram_bwd_gated(const float *D, const float *feat, int B, int C, int HW, float coef, int accumulate,
+                                   float *gfeat, st3d_stream_t stream) {
+    ST3D_CHECK_ARG(C % 32 == 0);        // the gate bits are picked up per 32-row block of the activation
+    return gram_bwd_launch(D, feat, B, C, HW, coef, accumulate, 1, gfeat, stream);
+}
+
+static int gram_bwd_launch(const float *D, const float *feat, int B, int C, int HW, float coef, int accumulate, int gate,
+                           float *gfeat, st3d_stream_t stream) {
     ST3D_CHECK_ARG(D && feat && gfeat);
     ST3D_CHECK_ARG(B > 0 && C > 0 && HW > 0);
     GemmArgs g;
     memset(&g, 0, sizeof(g));
+    g.gate = gate;
     g.A = D; g.B = feat; g.C = gfeat;
     g.M = C; g.N = HW; g.K = C; g.lda = C; g.ldb = HW; g.ldc = HW;
     g.sA = (size_t)C * C; g.sB = g.sC = (size_t)C * HW;

@@ -52,12 +52,15 @@ __global__ __launch_bounds__(256) void finish_kernel(const float *__restrict__ p
     if (threadIdx.x == 0) out[0] = out[0] + (float)(s[0] * (double)scale);
 }
 
+// gate: also zero the result where a <= 0 (a is a post-ReLU activation: the ReLU gate of the gradient that lives in g)
 __global__ __launch_bounds__(256) void axpy_diff_kernel(const float *__restrict__ a, const float *__restrict__ b, size_t n,
-                                                        float coef, int accumulate, float *__restrict__ g) {
+                                                        float coef, int accumulate, int gate, float *__restrict__ g) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const float v = coef * (a[i] - b[i]);
-        g[i] = accumulate ? g[i] + v : v;
+        const float ai = a[i];
+        const float v = coef * (ai - b[i]);
+        const float t = accumulate ? g[i] + v : v;
+        g[i] = (gate && !(ai > 0.f)) ? 0.f : t;
     }
 }
 
@@ -193,7 +196,15 @@ extern "C" int st3d_sqdiff_sum(const float *a, const float *b, size_t n, size_t 
 extern "C" int st3d_axpy_diff(const float *a, const float *b, size_t n, float coef, int accumulate, float *g,
                               st3d_stream_t stream) {
     ST3D_CHECK_ARG(a && b && g && n > 0);
-    axpy_diff_kernel<<<grid_for(n), 256, 0, st3d::as_stream(stream)>>>(a, b, n, coef, accumulate, g);
+    axpy_diff_kernel<<<grid_for(n), 256, 0, st3d::as_stream(stream)>>>(a, b, n, coef, accumulate, 0, g);
+    ST3D_LAUNCH_CHECK();
+    return ST3D_OK;
+}
+
+extern "C" int st3d_axpy_diff_gated(const float *a, const float *b, size_t n, float coef, int accumulate, float *g,
+                                    st3d_stream_t stream) {
+    ST3D_CHECK_ARG(a && b && g && n > 0);
+    axpy_diff_kernel<<<grid_for(n), 256, 0, st3d::as_stream(stream)>>>(a, b, n, coef, accumulate, 1, g);
     ST3D_LAUNCH_CHECK();
     return ST3D_OK;
 }

@@ -70,6 +70,7 @@ struct st3d_vgg {
     float *bias[16];
     bool set[16];
     bool use_wino;     // ST3D_CONV=direct forces the direct kernels (A/B runs)
+    bool pregate;      // ST3D_PREGATE=0: every input-gradient launch applies its own ReLU gate (A/B runs)
     bool fuse_tap0;    // ST3D_TAP0_FUSED=0: relu1_1 Gram backward and conv1_1 input gradient as separate launches (A/B runs)
 };
 
@@ -81,6 +82,8 @@ extern "C" int st3d_vgg_create(st3d_vgg **out) {
     v->use_wino = !(mode && strcmp(mode, "direct") == 0);
     const char *t0 = getenv("ST3D_TAP0_FUSED");
     v->fuse_tap0 = !(t0 && t0[0] == '0');
+    const char *pg = getenv("ST3D_PREGATE");
+    v->pregate = !(pg && pg[0] == '0');
     for (int i = 0; i < 16; ++i) {
         const size_t n = st3d_conv3x3_packed_floats(kConvCout[i], kConvCin[i]);
         bool ok = hipMalloc(&v->wf[i], n * sizeof(float)) == hipSuccess && hipMalloc(&v->wd[i], n * sizeof(float)) == hipSuccess &&
@@ -273,13 +276,28 @@ __global__ __launch_bounds__(256) void unpool_add_kernel(const float *__restrict
     }
 }
 
+bool dgrad_is_wino(const st3d_plan *p, int cs) {
+    const int m = kConvIdx[cs];
+    return p->vgg->use_wino && p->vgg->ud[cs] && st3d_wino_supported(kConvCout[cs], kConvCin[cs], p->H[m], p->W[m]);
+}
+
 // one input-gradient launch of conv slot cs: g (gradient w.r.t. the conv's post-ReLU output, or w.r.t. the output of
-// the pool behind it when pooled) -> dst (gradient w.r.t. the conv's input)
-int dgrad_step(st3d_plan *p, int cs, const float *g, bool g_is_pooled, int pool_of_g, float *dst, int n, hipStream_t s) {
+// the pool behind it when pooled) -> dst (gradient w.r.t. the conv's input).  pregated: g is already zero where the gate
+// this launch would apply is closed; out_gate: zero dst where this tensor is <= 0 (the next link's gate, Winograd only)
+int dgrad_step(st3d_plan *p, int cs, const float *g, bool g_is_pooled, int pool_of_g, float *dst, int n, hipStream_t s,
+               bool pregated = false, const float *out_gate = nullptr) {
     const int m = kConvIdx[cs];
     const int H = p->H[m], W = p->W[m];
-    const bool wino = p->vgg->use_wino && p->vgg->ud[cs] && st3d_wino_supported(kConvCout[cs], kConvCin[cs], H, W);
+    const bool wino = dgrad_is_wino(p, cs);
     Scope sc(p, wino ? F_CONV_DGRAD : F_CONVX_DGRAD, s, m);
+    if (wino && (pregated || out_gate)) {
+        const uint8_t *pidx = g_is_pooled ? p->pidx[pool_of_g] : nullptr;
+        const float *pooled = (g_is_pooled && !pregated) ? p->act[kPoolIdx[pool_of_g]] : nullptr;
+        const float *act = (!g_is_pooled && !pregated) ? p->act[m] : nullptr;
+        ST3D_TRY(st3d_wino_dgrad_chain(g, act, pidx, pooled, p->vgg->ud[cs], out_gate, dst, n, kConvCin[cs], kConvCout[cs], H,
+                                       W, s));
+        return ST3D_OK;
+    }
     if (g_is_pooled) {
         if (wino)
             ST3D_TRY(st3d_wino_dgrad_unpool(g, p->pidx[pool_of_g], p->act[kPoolIdx[pool_of_g]], p->vgg->ud[cs], dst, n,
@@ -538,7 +556,7 @@ static int plan_loss_enqueue(st3d_plan *p, const float *current, int n, int batc
 
     // ---- backward: gradient w.r.t. the post-ReLU output of each conv, top down
     float *g = p->gbuf[0], *gn = p->gbuf[1];
-    bool have_g = false, g_is_pooled = false;
+    bool have_g = false, g_is_pooled = false, g_gated = false;
     int pool_of_g = -1;
     for (int cs = 12; cs >= 0; --cs) {          // conv slots 12 (module 28) .. 0
         const int m = kConvIdx[cs];
@@ -555,20 +573,41 @@ static int plan_loss_enqueue(st3d_plan *p, const float *current, int n, int batc
                                     p->vgg->wd[0], gn, p->gbuf_floats * sizeof(float), grad_current, n, H, W, s));
             break;
         }
+        // Producer-side ReLU gates (st3d_wino_dgrad_chain): whoever writes a gradient last zeroes it where its tensor's gate
+        // is closed, so the Winograd input-gradient that consumes it streams one operand per stage
+        const bool chain = p->vgg->pregate && dgrad_is_wino(p, cs) && !g_is_pooled && (C % 32) == 0;
         if (st >= 0) {
             Scope sc(p, F_GRAM_BWD, s, m);
-            ST3D_TRY(st3d_gram_bwd(p->D[st], p->act[m], n, C, H * W, style_coef[st], have_g ? 1 : 0, g, s));
+            if (chain) {
+                ST3D_TRY(st3d_gram_bwd_gated(p->D[st], p->act[m], n, C, H * W, style_coef[st], have_g ? 1 : 0, g, s));
+                g_gated = true;
+            } else {
+                ST3D_TRY(st3d_gram_bwd(p->D[st], p->act[m], n, C, H * W, style_coef[st], have_g ? 1 : 0, g, s));
+                g_gated = false;
+            }
             have_g = true;
         }
         if (m == kContentTap) {
             Scope sc(p, F_ELEM, s);
-            ST3D_TRY(st3d_axpy_diff(p->act[m], p->content_target, (size_t)n * C * H * W,
-                                    (float)(2.0 * (double)content_weight / (bd * (double)chw)), have_g ? 1 : 0, g, s));
+            const float cc = (float)(2.0 * (double)content_weight / (bd * (double)chw));
+            if (chain) {
+                ST3D_TRY(st3d_axpy_diff_gated(p->act[m], p->content_target, (size_t)n * C * H * W, cc, have_g ? 1 : 0, g, s));
+                g_gated = true;
+            } else {
+                ST3D_TRY(st3d_axpy_diff(p->act[m], p->content_target, (size_t)n * C * H * W, cc, have_g ? 1 : 0, g, s));
+                g_gated = false;
+            }
             have_g = true;
         }
         if (!have_g) continue;
         float *dst = (cs == 0) ? grad_current : gn;
-        ST3D_TRY(dgrad_step(p, cs, g, g_is_pooled, pool_of_g, dst, n, s));
+        // the tensor dst is the gradient of = this conv's forward input (previous post-ReLU output, or the pool's output):
+        // gate it here when the launch that consumes it is a Winograd one
+        const float *og = nullptr;
+        if (p->vgg->pregate && cs > 0 && dgrad_is_wino(p, cs) && dgrad_is_wino(p, cs - 1))
+            og = p->act[pool_slot(m - 1) >= 0 ? m - 1 : m - 2];
+        ST3D_TRY(dgrad_step(p, cs, g, g_is_pooled, pool_of_g, dst, n, s, g_gated, og));
+        g_gated = og != nullptr;
         // dst is the gradient w.r.t. this conv's input: either the previous conv's post-ReLU
         // output or a pool output (then the next dgrad fuses the unpool)
         g_is_pooled = (m > 0) && pool_slot(m - 1) >= 0;

@@ -63,6 +63,8 @@ struct WinoArgs {
     int N, Cin, Cout, H, W, relu, tiles_x, tiles_y, n_ct;
     int tiles_per_xcd;    // wino4_kernel: pixel tiles owned by one XCD
     unsigned long long *dbg;   // diagnostic builds only (DBG != 0): per-wave phase cycle sums
+    const float *gate;    // wino4_kernel: (N,Cout,H,W) or nullptr; outputs are zeroed where gate <= 0 (the consumer's ReLU gate,
+                          // applied by the producer so that the consumer streams ONE operand: see st3d_wino_dgrad_chain)
 };
 
 // Wave roles (8 waves): a = wave & 3 is the row of the 4x4 Winograd domain the wave accumulates
@@ -467,7 +469,8 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
     const int H = a.H, W = a.W;
     const size_t HW = (size_t)H * W;
     const int Hp = H >> 1, Wp = W >> 1;
-    const size_t in_plane = (MODE == 2) ? (size_t)Hp * Wp : HW;
+    constexpr bool UNPOOL = MODE == 2 || MODE == 3;     // MODE 3: the pooled gradient arrives already gated (pooled value > 0)
+    const size_t in_plane = UNPOOL ? (size_t)Hp * Wp : HW;
     const int nstages = a.Cin / KS;
 
     // staging: 8 channels x 6 rows x 10 sixteen-byte items = 480 items per stage, two per thread
@@ -475,7 +478,7 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
     const unsigned kOob = 0x80000000u;
     unsigned voff[IPT];
     int loff[IPT];
-    unsigned rowbit[MODE == 2 ? IPT : 1];
+    unsigned rowbit[UNPOOL ? IPT : 1];
 #pragma unroll
     for (int i = 0; i < IPT; ++i) {
         const int e = tid + i * NT4;
@@ -483,7 +486,7 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
         const int r = rem / 10, l = rem - r * 10;
         const int gy = y0 + r - 1, gx0 = x0 - 4 + 4 * l;
         const bool ok = e < ITEMS && gy >= 0 && gy < H && gx0 >= 0 && gx0 < W;
-        if (MODE == 2) {
+        if (UNPOOL) {
             voff[i] = ok ? (unsigned)((ci * in_plane + (size_t)(gy >> 1) * Wp + (gx0 >> 1)) * 4) : kOob;
             rowbit[i] = (gy & 1) << 1;
         } else {
@@ -496,9 +499,9 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(a.x + (size_t)n * a.Cin * in_plane), 0, img_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t raux = rx, ridx = rx;
-    if (MODE != 0)
+    if (MODE == 1 || MODE == 2)
         raux = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.aux + (size_t)n * a.Cin * in_plane), 0, img_bytes, 0x00020000);
-    if (MODE == 2)
+    if (UNPOOL)
         ridx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.idx + (size_t)n * a.Cin * in_plane), 0, img_bytes / 4, 0x00020000);
     const int nsub = a.Cin / KC;
     const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(
@@ -507,16 +510,16 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
 
     f32x4 xv[IPT];
     f32x4 xa[MODE == 1 ? IPT : 1];
-    f32x2 xg[MODE == 2 ? IPT : 1], xp[MODE == 2 ? IPT : 1];
-    unsigned xi[MODE == 2 ? IPT : 1];
+    f32x2 xg[UNPOOL ? IPT : 1], xp[MODE == 2 ? IPT : 1];
+    unsigned xi[UNPOOL ? IPT : 1];
 
     auto gload = [&](int st) __attribute__((always_inline)) {
         const unsigned so = (unsigned)st * stage_bytes;
 #pragma unroll
         for (int i = 0; i < IPT; ++i) {
-            if (MODE == 2) {
+            if (UNPOOL) {
                 xg[i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rx, voff[i], so, 0));
-                xp[i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(raux, voff[i], so, 0));
+                if (MODE == 2) xp[i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(raux, voff[i], so, 0));
                 xi[i] = __builtin_amdgcn_raw_buffer_load_b16(ridx, voff[i] == kOob ? kOob : voff[i] / 4, so / 4, 0);
             } else {
                 xv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff[i], so, 0));
@@ -538,6 +541,10 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
                     if (MODE == 2) {
                         const unsigned ib = (xi[i] >> (8 * (jj >> 1))) & 0xffu;
                         v = (xp[i][jj >> 1] > 0.f && ib == (rowbit[i] | (jj & 1))) ? xg[i][jj >> 1] : 0.f;
+                    }
+                    if (MODE == 3) {
+                        const unsigned ib = (xi[i] >> (8 * (jj >> 1))) & 0xffu;
+                        v = (ib == (rowbit[i] | (jj & 1))) ? xg[i][jj >> 1] : 0.f;
                     }
                     dst[jj] = v;
                 }
@@ -673,10 +680,21 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
                 const int co = mh * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                 ex[((jj * 4 + wa) * 64 + co) * 32 + l31] = z;
             }
-    __syncthreads();
     const int pair = tid & 15;                        // tiles 2 * pair, 2 * pair + 1 (same tile row)
     const int oy = y0 + 2 * (pair >> 3), ox = x0 + 4 * (pair & 7);
     const bool inb = oy < H && ox < W;                // H even, W % 4 == 0: the 2 x 4 pixel item is inside or outside
+    // the consumer's ReLU gate, applied here (a.gate: the tensor this gradient belongs to): fetched now -- the accumulators
+    // are dead, and a load issued between the stores below would queue behind them -- and used after the exchange
+    f32x4 gq[4][2];
+    if (EPI == 0 && a.gate) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const float *gp = a.gate + ((size_t)n * a.Cout + co0 + it * 16 + (tid >> 4)) * HW + (size_t)oy * W + ox;
+            gq[it][0] = inb ? *reinterpret_cast<const f32x4 *>(gp) : f32x4{0.f, 0.f, 0.f, 0.f};
+            gq[it][1] = inb ? *reinterpret_cast<const f32x4 *>(gp + W) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    __syncthreads();
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int col = it * 16 + (tid >> 4);         // cout within the workgroup's 64
@@ -706,6 +724,13 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
             f32x4 q0, q1;
             q0[0] = y[0][0][0]; q0[1] = y[0][0][1]; q0[2] = y[1][0][0]; q0[3] = y[1][0][1];
             q1[0] = y[0][1][0]; q1[1] = y[0][1][1]; q1[2] = y[1][1][0]; q1[3] = y[1][1][1];
+            if (EPI == 0 && a.gate) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    q0[e] = gq[it][0][e] > 0.f ? q0[e] : 0.f;
+                    q1[e] = gq[it][1][e] > 0.f ? q1[e] : 0.f;
+                }
+            }
             *reinterpret_cast<f32x4 *>(dst) = q0;
             *reinterpret_cast<f32x4 *>(dst + W) = q1;
         }
@@ -789,7 +814,7 @@ int launch_wino4(WinoArgs a, hipStream_t s) {
     // input-gradient, whose pooled-resolution operands are a quarter of the size (measured 2-4 % faster there).
     // ST3D_WINO_MAP=rr / xcd forces one mapping (A/B runs).
     static const int forced = [] { const char *e = getenv("ST3D_WINO_MAP"); return !e ? 0 : (strcmp(e, "rr") == 0 ? 1 : 2); }();
-    const bool rr = forced ? forced == 1 : MODE == 2;
+    const bool rr = forced ? forced == 1 : (MODE == 2 || MODE == 3);
     a.tiles_per_xcd = rr ? 0 : (int)((ntiles + 7) / 8);
     const long blocks = rr ? ntiles * a.n_ct : 8L * a.tiles_per_xcd * a.n_ct;   // bid & 7 = XCD, bid >> 3 = (pixel tile in the XCD's run, cout tile)
 #ifdef ST3D_WINO_DEBUG
@@ -811,7 +836,7 @@ int launch_wino4(WinoArgs a, hipStream_t s) {
 
 template <int MODE>
 int launch_wino(WinoArgs a, hipStream_t s) {
-    if (wino_variant(a) == 4 && !a.dbg) return launch_wino4<MODE>(a, s);
+    if ((wino_variant(a) == 4 && !a.dbg) || a.gate) return launch_wino4<MODE>(a, s);      // the output gate exists in wino4 only
     a.tiles_x = st3d::cdiv(a.W, TCOLS);
     a.tiles_y = st3d::cdiv(a.H, TROWS);
     a.n_ct = a.Cout / BCO;
@@ -868,6 +893,20 @@ extern "C" int st3d_wino_dgrad(const float *gy, const float *act, const float *u
     ST3D_CHECK_ARG(((uintptr_t)u_dgrad & 15) == 0);
     WinoArgs a{gy, act, nullptr, u_dgrad, nullptr, gx, nullptr, nullptr, N, Cout, Cin, H, W, 0, 0, 0, 0, 0, nullptr};
     return act ? launch_wino<1>(a, st3d::as_stream(stream)) : launch_wino<0>(a, st3d::as_stream(stream));
+}
+
+extern "C" int st3d_wino_dgrad_chain(const float *gy, const float *act, const uint8_t *pool_idx, const float *pooled,
+                                     const float *u_dgrad, const float *out_gate, float *gx, int N, int Cin, int Cout, int H,
+                                     int W, st3d_stream_t stream) {
+    ST3D_CHECK_ARG(gy && u_dgrad && gx);
+    ST3D_CHECK_ARG(N > 0 && shape_ok(Cout, Cin, H, W));
+    ST3D_CHECK_ARG(((uintptr_t)u_dgrad & 15) == 0 && ((uintptr_t)out_gate & 15) == 0);
+    ST3D_CHECK_ARG(!(pool_idx && act));            // a pooled gradient is gated by `pooled`, a full-resolution one by `act`
+    WinoArgs a{gy, pool_idx ? pooled : act, pool_idx, u_dgrad, nullptr, gx, nullptr, nullptr, N, Cout, Cin, H, W, 0, 0, 0, 0, 0,
+               nullptr, out_gate};
+    hipStream_t s = st3d::as_stream(stream);
+    if (pool_idx) return pooled ? launch_wino4<2>(a, s) : launch_wino4<3>(a, s);
+    return act ? launch_wino<1>(a, s) : launch_wino<0>(a, s);
 }
 
 extern "C" int st3d_wino_dgrad_unpool(const float *gy_pooled, const uint8_t *pool_idx, const float *pooled,

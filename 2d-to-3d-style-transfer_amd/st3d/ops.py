@@ -353,6 +353,16 @@ def wino_dgrad_unpool(gy_pooled, pool_idx, pooled, ud, Cin):
     return gx
 
 
+def wino_dgrad_chain(gy, ud, Cin, act=None, pool_idx=None, pooled=None, out_gate=None):
+    """One link of the producer-gated backward chain (st3d_wino_dgrad_chain)."""
+    N, Cout = gy.shape[:2]
+    H, W = (2 * gy.shape[2], 2 * gy.shape[3]) if pool_idx is not None else gy.shape[2:]
+    gx = torch.empty((N, Cin, H, W), dtype=F32, device=gy.device)
+    call("st3d_wino_dgrad_chain", dptr(gy.contiguous(), F32), dptr(act, F32), dptr(pool_idx, U8), dptr(pooled, F32),
+         dptr(ud, F32), dptr(out_gate, F32), dptr(gx), N, Cin, Cout, H, W, stream_ptr())
+    return gx
+
+
 def maxpool2x2(y, want_idx=True):
     N, C, H, W = y.shape
     p = torch.empty((N, C, H // 2, W // 2), dtype=F32, device=y.device)
@@ -373,14 +383,15 @@ def gram_fwd(feat):
     return g
 
 
-def gram_bwd(D, feat, coef, out=None):
+def gram_bwd(D, feat, coef, out=None, gated=False):
+    """out (+)= coef * D feat; gated: then zeroed where feat <= 0 (st3d_gram_bwd_gated)."""
     B, C = feat.shape[:2]
     HW = feat[0, 0].numel()
     acc = 1
     if out is None:
         out = torch.empty_like(feat)
         acc = 0
-    call("st3d_gram_bwd", dptr(D.contiguous(), F32), dptr(feat.contiguous(), F32), B, C, HW, float(coef), acc, dptr(out),
+    call("st3d_gram_bwd_gated" if gated else "st3d_gram_bwd", dptr(D.contiguous(), F32), dptr(feat.contiguous(), F32), B, C, HW, float(coef), acc, dptr(out),
          stream_ptr())
     return out
 

@@ -204,6 +204,15 @@ int st3d_wino_dgrad(const float *gy, const float *act, const float *u_dgrad, flo
 int st3d_wino_dgrad_unpool(const float *gy_pooled, const uint8_t *pool_idx, const float *pooled,
                            const float *u_dgrad, float *gx, int N, int Cin, int Cout, int H, int W,
                            st3d_stream_t stream);
+/* One link of the backward chain with the ReLU gates moved to the PRODUCER of each gradient, so that the 8-64 stages of
+ * the consumer's K loop stream one operand instead of two or three (measured 3-13 % per launch):
+ *   input : gy, full resolution gated by act (NULL = gy is already gated), or -- pool_idx != NULL -- at pooled resolution,
+ *           un-pooled through pool_idx and gated by pooled > 0 (pooled == NULL = already gated);
+ *   output: gx = conv^T(...), zeroed where out_gate (N,Cin,H,W: the conv's own forward input, post-ReLU or pool output)
+ *           is <= 0 when out_gate != NULL -- i.e. gx is handed on already gated for the next link. */
+int st3d_wino_dgrad_chain(const float *gy, const float *act, const uint8_t *pool_idx, const float *pooled,
+                          const float *u_dgrad, const float *out_gate, float *gx, int N, int Cin, int Cout,
+                          int H, int W, st3d_stream_t stream);
 /* MaxPool2d(2,2): y (N,C,H,W) -> p (N,C,H/2,W/2) (+ argmax idx, may be NULL) */
 int st3d_maxpool2x2_fwd(const float *y, float *p, uint8_t *idx, int N, int C, int H, int W,
                         st3d_stream_t stream);
@@ -220,6 +229,10 @@ int st3d_gram_fwd(const float *feat, int B, int C, int HW, void *workspace, size
  * into gfeat. */
 int st3d_gram_bwd(const float *D, const float *feat, int B, int C, int HW, float coef,
                   int accumulate, float *gfeat, st3d_stream_t stream);
+/* the same, then gfeat = 0 where feat <= 0 (feat is post-ReLU: its ReLU gate, taken from the operand tile already in
+ * LDS), so the gradient leaves already gated (see st3d_wino_dgrad_chain).  C % 32 == 0. */
+int st3d_gram_bwd_gated(const float *D, const float *feat, int B, int C, int HW, float coef,
+                        int accumulate, float *gfeat, st3d_stream_t stream);
 /* loss_out[0] += scale * sum((a-b)^2) over n elements (b broadcast with period nb, nb | n);
  * if D != NULL also D = a - b.  Deterministic two-stage reduction through `partials`
  * (>= st3d_reduce_partials() floats). */
@@ -229,6 +242,10 @@ int st3d_sqdiff_sum(const float *a, const float *b, size_t n, size_t nb, float s
 /* content loss backward: g (+)= coef * (a - b)  */
 int st3d_axpy_diff(const float *a, const float *b, size_t n, float coef, int accumulate, float *g,
                    st3d_stream_t stream);
+/* the same, then g = 0 where a <= 0: a is the post-ReLU activation the gradient g belongs to, so g leaves already gated
+ * (see st3d_wino_dgrad_chain) */
+int st3d_axpy_diff_gated(const float *a, const float *b, size_t n, float coef, int accumulate, float *g,
+                         st3d_stream_t stream);
 /* masked MSE of losses.py:68-75 ('texture' branch): loss_out[0] = mean((r*m - t*m)^2) over
  * B*3*S*S; grad_r = 2*m*m*(r - t)/(B*3*S*S) (may be NULL). */
 int st3d_masked_mse(const float *rendered, const float *target, const float *mask, int B, int S,

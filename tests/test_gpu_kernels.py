@@ -811,3 +811,80 @@ def test_rasterisers_match_oracle_on_random_triangle_soups(dev, ops, seed, F, S)
                               z_clip=zc, return_slots=zc is not None)
         for g, r in zip(got, want):
             np.testing.assert_array_equal(g[0].cpu().numpy(), r, err_msg=str((K, blur, cull, persp, zc)))
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 64, 64, 32, 64), (1, 128, 256, 16, 24), (1, 64, 128, 160, 96)])
+def test_producer_gated_backward_chain_is_bitwise_the_consumer_gated_one(dev, ops, N, Cin, Cout, H, W):
+    """st3d_wino_dgrad_chain moves the ReLU gates to the producer of each gradient.  Zeros are zeros: every variant must
+    be BITWISE what the consumer-gated launches (st3d_wino_dgrad / st3d_wino_dgrad_unpool, themselves checked against
+    autograd above) return on the same data.
+      input side : gy pre-multiplied by its gate + act=None            == gy gated by act in the kernel
+                   pooled gy pre-gated by pooled > 0 + pooled=None     == gated by pooled in the kernel
+      output side: out_gate                                            == the plain launch, then zeroed where gate <= 0"""
+    g = torch.Generator().manual_seed(H + W + Cin)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5).to(dev)
+    _, ud = ops.wino_pack(w)
+    act = torch.relu(torch.randn(N, Cout, H, W, generator=g)).to(dev)           # about half the gates closed
+    gy = torch.randn(N, Cout, H, W, generator=g).to(dev)
+    out_gate = torch.relu(torch.randn(N, Cin, H, W, generator=g)).to(dev)
+    ref = ops.wino_dgrad(gy, act, ud, Cin)
+    pre = torch.where(act > 0, gy, torch.zeros_like(gy))
+    assert torch.equal(ops.wino_dgrad_chain(pre, ud, Cin), ref)
+    assert torch.equal(ops.wino_dgrad_chain(gy, ud, Cin, act=act), ref)
+    want = torch.where(out_gate > 0, ref, torch.zeros_like(ref))
+    assert torch.equal(ops.wino_dgrad_chain(gy, ud, Cin, act=act, out_gate=out_gate), want)
+    assert torch.equal(ops.wino_dgrad_chain(pre, ud, Cin, out_gate=out_gate), want)
+    # pooled input
+    full = torch.relu(torch.randn(N, Cout, H, W, generator=g)).to(dev)
+    pooled, idx = ops.maxpool2x2(full)
+    gp = torch.randn(N, Cout, H // 2, W // 2, generator=g).to(dev)
+    ref2 = ops.wino_dgrad_unpool(gp, idx, pooled, ud, Cin)
+    gp_pre = torch.where(pooled > 0, gp, torch.zeros_like(gp))
+    assert torch.equal(ops.wino_dgrad_chain(gp, ud, Cin, pool_idx=idx, pooled=pooled), ref2)
+    assert torch.equal(ops.wino_dgrad_chain(gp_pre, ud, Cin, pool_idx=idx), ref2)
+    want2 = torch.where(out_gate > 0, ref2, torch.zeros_like(ref2))
+    assert torch.equal(ops.wino_dgrad_chain(gp_pre, ud, Cin, pool_idx=idx, out_gate=out_gate), want2)
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 64, 64, 64), (1, 128, 40, 40), (2, 256, 16, 16), (1, 512, 8, 8), (1, 512, 32, 32),
+                                     (1, 128, 256, 256), (1, 96, 20, 12)])
+def test_gram_bwd_gated_zeroes_exactly_the_closed_gates(dev, ops, B, C, H, W):
+    """st3d_gram_bwd_gated == st3d_gram_bwd followed by `where(feat > 0, ., 0)`, bitwise, with and without accumulation
+    (the gate bits come from the operand tile in LDS; every tile shape the launcher picks is covered)."""
+    g = torch.Generator().manual_seed(C + H)
+    feat = torch.relu(torch.randn(B, C, H, W, generator=g)).to(dev)
+    D = torch.randn(B, C, C, generator=g)
+    D = (0.5 * (D + D.transpose(1, 2))).to(dev).contiguous()
+    base = torch.randn(B, C, H, W, generator=g).to(dev)
+    zero = torch.zeros_like(feat)
+    assert torch.equal(ops.gram_bwd(D, feat, 0.3, gated=True), torch.where(feat > 0, ops.gram_bwd(D, feat, 0.3), zero))
+    assert torch.equal(ops.gram_bwd(D, feat, 0.3, out=base.clone(), gated=True),
+                       torch.where(feat > 0, ops.gram_bwd(D, feat, 0.3, out=base.clone()), zero))
+
+
+def test_plan_backward_with_producer_side_gates_is_bitwise_the_plain_one(dev, golden_dir, monkeypatch):
+    """The loss plan's backward with the gates at the producers + the fused relu1_1/conv1_1 kernel (defaults) against
+    ST3D_PREGATE=0 (bitwise: zeros are zeros) and against ST3D_TAP0_FUSED=0 (another summation order: 1e-5)."""
+    from st3d import vgg as V
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(2, 3, 64, 64, generator=g).to(dev)
+    con = torch.rand(2, 3, 64, 64, generator=g).to(dev)
+    sty = torch.rand(1, 3, 64, 64, generator=g).to(dev)
+
+    def run(env):
+        for k in ("ST3D_PREGATE", "ST3D_TAP0_FUSED"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        net = V.Vgg19Features(V.synthetic_state(0), device=dev)        # the switches are read when the VGG handle is made
+        plan = net.plan(2, 64)
+        plan.set_content(con)
+        plan.set_style(sty, 2)
+        loss, grad = plan.loss(x, 1e6, 1.0)
+        return loss.clone(), grad.clone()
+    l0, g0 = run({})
+    l1, g1 = run({"ST3D_PREGATE": "0"})
+    l2, g2 = run({"ST3D_PREGATE": "0", "ST3D_TAP0_FUSED": "0"})
+    assert torch.equal(l0, l1) and torch.equal(g0, g1)
+    assert torch.equal(l0, l2)
+    _scale_close(g0, g2, 1e-5, "fused vs unfused bottom of the backward")
