@@ -285,7 +285,7 @@ bool dgrad_is_wino(const st3d_plan *p, int cs) {
 // the pool behind it when pooled) -> dst (gradient w.r.t. the conv's input).  pregated: g is already zero where the gate
 // this launch would apply is closed; out_gate: zero dst where this tensor is <= 0 (the next link's gate, Winograd only)
 int dgrad_step(st3d_plan *p, int cs, const float *g, bool g_is_pooled, int pool_of_g, float *dst, int n, hipStream_t s,
-               bool pregated = false, const float *out_gate = nullptr) {
+               bool pregated = false, const float *out_gate = nullptr, const float *add_target = nullptr, float add_coef = 0.f) {
     const int m = kConvIdx[cs];
     const int H = p->H[m], W = p->W[m];
     const bool wino = dgrad_is_wino(p, cs);
@@ -294,8 +294,8 @@ int dgrad_step(st3d_plan *p, int cs, const float *g, bool g_is_pooled, int pool_
         const uint8_t *pidx = g_is_pooled ? p->pidx[pool_of_g] : nullptr;
         const float *pooled = (g_is_pooled && !pregated) ? p->act[kPoolIdx[pool_of_g]] : nullptr;
         const float *act = (!g_is_pooled && !pregated) ? p->act[m] : nullptr;
-        ST3D_TRY(st3d_wino_dgrad_chain(g, act, pidx, pooled, p->vgg->ud[cs], out_gate, dst, n, kConvCin[cs], kConvCout[cs], H,
-                                       W, s));
+        ST3D_TRY(st3d_wino_dgrad_chain(g, act, pidx, pooled, p->vgg->ud[cs], out_gate, add_target, add_coef, dst, n,
+                                       kConvCin[cs], kConvCout[cs], H, W, s));
         return ST3D_OK;
     }
     if (g_is_pooled) {
@@ -556,8 +556,9 @@ static int plan_loss_enqueue(st3d_plan *p, const float *current, int n, int batc
 
     // ---- backward: gradient w.r.t. the post-ReLU output of each conv, top down
     float *g = p->gbuf[0], *gn = p->gbuf[1];
-    bool have_g = false, g_is_pooled = false, g_gated = false;
+    bool have_g = false, g_is_pooled = false, g_gated = false, content_done = false;
     int pool_of_g = -1;
+    const float cc = (float)(2.0 * (double)content_weight / (bd * (double)chw));       // d content / d conv4_2 = cc * (F - target)
     for (int cs = 12; cs >= 0; --cs) {          // conv slots 12 (module 28) .. 0
         const int m = kConvIdx[cs];
         const int C = p->C[m], H = p->H[m], W = p->W[m];
@@ -587,9 +588,8 @@ static int plan_loss_enqueue(st3d_plan *p, const float *current, int n, int batc
             }
             have_g = true;
         }
-        if (m == kContentTap) {
+        if (m == kContentTap && !content_done) {
             Scope sc(p, F_ELEM, s);
-            const float cc = (float)(2.0 * (double)content_weight / (bd * (double)chw));
             if (chain) {
                 ST3D_TRY(st3d_axpy_diff_gated(p->act[m], p->content_target, (size_t)n * C * H * W, cc, have_g ? 1 : 0, g, s));
                 g_gated = true;
@@ -603,10 +603,14 @@ static int plan_loss_enqueue(st3d_plan *p, const float *current, int n, int batc
         float *dst = (cs == 0) ? grad_current : gn;
         // the tensor dst is the gradient of = this conv's forward input (previous post-ReLU output, or the pool's output):
         // gate it here when the launch that consumes it is a Winograd one
-        const float *og = nullptr;
+        const float *og = nullptr, *addt = nullptr;
         if (p->vgg->pregate && cs > 0 && dgrad_is_wino(p, cs) && dgrad_is_wino(p, cs - 1))
             og = p->act[pool_slot(m - 1) >= 0 ? m - 1 : m - 2];
-        ST3D_TRY(dgrad_step(p, cs, g, g_is_pooled, pool_of_g, dst, n, s, g_gated, og));
+        if (og && m - 2 == kContentTap) {       // dst is the gradient of the content tap: its own term joins in this launch's store
+            addt = p->content_target;
+            content_done = true;
+        }
+        ST3D_TRY(dgrad_step(p, cs, g, g_is_pooled, pool_of_g, dst, n, s, g_gated, og, addt, cc));
         g_gated = og != nullptr;
         // dst is the gradient w.r.t. this conv's input: either the previous conv's post-ReLU
         // output or a pool output (then the next dgrad fuses the unpool)

@@ -65,6 +65,8 @@ struct WinoArgs {
     unsigned long long *dbg;   // diagnostic builds only (DBG != 0): per-wave phase cycle sums
     const float *gate;    // wino4_kernel: (N,Cout,H,W) or nullptr; outputs are zeroed where gate <= 0 (the consumer's ReLU gate,
                           // applied by the producer so that the consumer streams ONE operand: see st3d_wino_dgrad_chain)
+    const float *addt;    // with gate: outputs become gate > 0 ? y + addc * (gate - addt) : 0 -- the content-loss gradient
+    float addc;           // addc * (activation - target) (losses.py:24-28) lands in the same store; nullptr = none
 };
 
 // Wave roles (8 waves): a = wave & 3 is the row of the 4x4 Winograd domain the wave accumulates
@@ -694,6 +696,15 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
             gq[it][1] = inb ? *reinterpret_cast<const f32x4 *>(gp + W) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
+    f32x4 tq[4][2];
+    if (EPI == 0 && a.gate && a.addt) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const float *tp = a.addt + ((size_t)n * a.Cout + co0 + it * 16 + (tid >> 4)) * HW + (size_t)oy * W + ox;
+            tq[it][0] = inb ? *reinterpret_cast<const f32x4 *>(tp) : f32x4{0.f, 0.f, 0.f, 0.f};
+            tq[it][1] = inb ? *reinterpret_cast<const f32x4 *>(tp + W) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -725,6 +736,14 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
             q0[0] = y[0][0][0]; q0[1] = y[0][0][1]; q0[2] = y[1][0][0]; q0[3] = y[1][0][1];
             q1[0] = y[0][1][0]; q1[1] = y[0][1][1]; q1[2] = y[1][1][0]; q1[3] = y[1][1][1];
             if (EPI == 0 && a.gate) {
+                if (a.addt) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        // unfused multiply / add: bitwise what st3d_axpy_diff (built without contraction) adds
+                        q0[e] = __fadd_rn(q0[e], __fmul_rn(a.addc, __fsub_rn(gq[it][0][e], tq[it][0][e])));
+                        q1[e] = __fadd_rn(q1[e], __fmul_rn(a.addc, __fsub_rn(gq[it][1][e], tq[it][1][e])));
+                    }
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     q0[e] = gq[it][0][e] > 0.f ? q0[e] : 0.f;
@@ -896,14 +915,15 @@ extern "C" int st3d_wino_dgrad(const float *gy, const float *act, const float *u
 }
 
 extern "C" int st3d_wino_dgrad_chain(const float *gy, const float *act, const uint8_t *pool_idx, const float *pooled,
-                                     const float *u_dgrad, const float *out_gate, float *gx, int N, int Cin, int Cout, int H,
-                                     int W, st3d_stream_t stream) {
+                                     const float *u_dgrad, const float *out_gate, const float *add_target, float add_coef,
+                                     float *gx, int N, int Cin, int Cout, int H, int W, st3d_stream_t stream) {
     ST3D_CHECK_ARG(gy && u_dgrad && gx);
     ST3D_CHECK_ARG(N > 0 && shape_ok(Cout, Cin, H, W));
-    ST3D_CHECK_ARG(((uintptr_t)u_dgrad & 15) == 0 && ((uintptr_t)out_gate & 15) == 0);
+    ST3D_CHECK_ARG(((uintptr_t)u_dgrad & 15) == 0 && ((uintptr_t)out_gate & 15) == 0 && ((uintptr_t)add_target & 15) == 0);
     ST3D_CHECK_ARG(!(pool_idx && act));            // a pooled gradient is gated by `pooled`, a full-resolution one by `act`
+    ST3D_CHECK_ARG(!add_target || out_gate);       // the added term is addc * (out_gate - add_target)
     WinoArgs a{gy, pool_idx ? pooled : act, pool_idx, u_dgrad, nullptr, gx, nullptr, nullptr, N, Cout, Cin, H, W, 0, 0, 0, 0, 0,
-               nullptr, out_gate};
+               nullptr, out_gate, add_target, add_coef};
     hipStream_t s = st3d::as_stream(stream);
     if (pool_idx) return pooled ? launch_wino4<2>(a, s) : launch_wino4<3>(a, s);
     return act ? launch_wino<1>(a, s) : launch_wino<0>(a, s);

@@ -69,8 +69,8 @@ SIGNATURES = {
     "st3d_wino_dgrad": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_stream]),
     "st3d_wino_dgrad_unpool": (c_int, [c_f32p, c_u8p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int,
                                        c_stream]),
-    "st3d_wino_dgrad_chain": (c_int, [c_f32p, c_f32p, c_u8p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int,
-                                      c_stream]),
+    "st3d_wino_dgrad_chain": (c_int, [c_f32p, c_f32p, c_u8p, c_f32p, c_f32p, c_f32p, c_f32p, c_float, c_f32p, c_int, c_int, c_int,
+                                      c_int, c_int, c_stream]),
     "st3d_maxpool2x2_fwd": (c_int, [c_f32p, c_f32p, c_u8p, c_int, c_int, c_int, c_int, c_stream]),
     "st3d_gram_workspace_bytes": (c_size, [c_int, c_int, c_int]),
     "st3d_gram_fwd": (c_int, [c_f32p, c_int, c_int, c_int, ctypes.c_void_p, c_size, c_f32p, c_stream]),

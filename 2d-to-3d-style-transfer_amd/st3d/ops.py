@@ -353,13 +353,13 @@ def wino_dgrad_unpool(gy_pooled, pool_idx, pooled, ud, Cin):
     return gx
 
 
-def wino_dgrad_chain(gy, ud, Cin, act=None, pool_idx=None, pooled=None, out_gate=None):
+def wino_dgrad_chain(gy, ud, Cin, act=None, pool_idx=None, pooled=None, out_gate=None, add_target=None, add_coef=0.0):
     """One link of the producer-gated backward chain (st3d_wino_dgrad_chain)."""
     N, Cout = gy.shape[:2]
     H, W = (2 * gy.shape[2], 2 * gy.shape[3]) if pool_idx is not None else gy.shape[2:]
     gx = torch.empty((N, Cin, H, W), dtype=F32, device=gy.device)
     call("st3d_wino_dgrad_chain", dptr(gy.contiguous(), F32), dptr(act, F32), dptr(pool_idx, U8), dptr(pooled, F32),
-         dptr(ud, F32), dptr(out_gate, F32), dptr(gx), N, Cin, Cout, H, W, stream_ptr())
+         dptr(ud, F32), dptr(out_gate, F32), dptr(add_target, F32), float(add_coef), dptr(gx), N, Cin, Cout, H, W, stream_ptr())
     return gx
 
 

@@ -209,10 +209,12 @@ int st3d_wino_dgrad_unpool(const float *gy_pooled, const uint8_t *pool_idx, cons
  *   input : gy, full resolution gated by act (NULL = gy is already gated), or -- pool_idx != NULL -- at pooled resolution,
  *           un-pooled through pool_idx and gated by pooled > 0 (pooled == NULL = already gated);
  *   output: gx = conv^T(...), zeroed where out_gate (N,Cin,H,W: the conv's own forward input, post-ReLU or pool output)
- *           is <= 0 when out_gate != NULL -- i.e. gx is handed on already gated for the next link. */
+ *           is <= 0 when out_gate != NULL -- i.e. gx is handed on already gated for the next link.  With add_target
+ *           (same shape, needs out_gate) the content-loss gradient add_coef * (out_gate - add_target) of that tensor
+ *           (losses.py:24-28; what st3d_axpy_diff adds) joins gx before the gate, in the same store. */
 int st3d_wino_dgrad_chain(const float *gy, const float *act, const uint8_t *pool_idx, const float *pooled,
-                          const float *u_dgrad, const float *out_gate, float *gx, int N, int Cin, int Cout,
-                          int H, int W, st3d_stream_t stream);
+                          const float *u_dgrad, const float *out_gate, const float *add_target, float add_coef,
+                          float *gx, int N, int Cin, int Cout, int H, int W, st3d_stream_t stream);
 /* MaxPool2d(2,2): y (N,C,H,W) -> p (N,C,H/2,W/2) (+ argmax idx, may be NULL) */
 int st3d_maxpool2x2_fwd(const float *y, float *p, uint8_t *idx, int N, int C, int H, int W,
                         st3d_stream_t stream);

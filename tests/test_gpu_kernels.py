@@ -834,6 +834,10 @@ def test_producer_gated_backward_chain_is_bitwise_the_consumer_gated_one(dev, op
     want = torch.where(out_gate > 0, ref, torch.zeros_like(ref))
     assert torch.equal(ops.wino_dgrad_chain(gy, ud, Cin, act=act, out_gate=out_gate), want)
     assert torch.equal(ops.wino_dgrad_chain(pre, ud, Cin, out_gate=out_gate), want)
+    # + the content-loss term of the output tensor (what st3d_axpy_diff adds), before the gate
+    target = torch.randn(N, Cin, H, W, generator=g).to(dev)
+    want3 = torch.where(out_gate > 0, ref + 0.25 * (out_gate - target), torch.zeros_like(ref))
+    assert torch.equal(ops.wino_dgrad_chain(pre, ud, Cin, out_gate=out_gate, add_target=target, add_coef=0.25), want3)
     # pooled input
     full = torch.relu(torch.randn(N, Cout, H, W, generator=g)).to(dev)
     pooled, idx = ops.maxpool2x2(full)
