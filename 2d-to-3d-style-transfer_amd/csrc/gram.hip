@@ -247,7 +247,9 @@ int gram_split(int B, int C, int HW, int *kper) {
     const int pairs = nt * (nt + 1) / 2;
     // workgroups aimed for, measured per style layer of config 2 (tools/gram_sweep.py): the deep layers (few tiles,
     // short K) want more, thinner splits; C = 128 fewer
-    const int target = C >= 256 ? 2048 : (C == 128 ? 512 : 1024);
+    // (round 2 re-measured with the split count itself, ST3D_GRAM_NSPLIT: 256 channels at 128^2 32 splits 145 vs 162 us at
+    // 64; 512 at 64^2 16 splits 144 vs 149 at 26; 512 at 32^2 8 splits 69 vs 76 at 4)
+    const int target = C >= 512 ? 1280 : (C == 256 ? 768 : (C == 128 ? 512 : 1024));
     int ns = (target + pairs * B - 1) / (pairs * B);
     if (const char *ev = getenv("ST3D_GRAM_TARGET_WGS")) {       // tuning knob (tools/gram_sweep.py): workgroups aimed for
         const int t = atoi(ev);
@@ -255,9 +257,13 @@ int gram_split(int B, int C, int HW, int *kper) {
     }
     const int ns_bytes = (HW + 2047) / 2048;            // never more than 2048 pixels per workgroup
     if (ns < ns_bytes) ns = ns_bytes;
-    const int ns_max = (HW + 8 * KCH0 - 1) / (8 * KCH0);   // at least 8 K-chunks (256 pixels) of work per workgroup (4 measured slower)
+    const int ns_max = (HW + 4 * KCH0 - 1) / (4 * KCH0);   // at least 4 K-chunks (128 pixels) of work per workgroup
     if (ns > ns_max) ns = ns_max;
     if (ns > 256) ns = 256;
+    if (const char *ev = getenv("ST3D_GRAM_NSPLIT")) {           // tuning knob (tools/gram_sweep.py): the split count itself
+        const int t = atoi(ev);
+        if (t > 0) ns = t;
+    }
     if (ns < 1) ns = 1;
     int kp = (HW + ns - 1) / ns;
     kp = (kp + KCH0 - 1) / KCH0 * KCH0;
@@ -337,7 +343,9 @@ static int gram_bwd_launch(const float *D, const float *feat, int B, int C, int 
     if (force && force[0] == '2' && C % 128 == 0) tall = true;
     // C = 128 at large HW: 128 rows x 64 pixels per workgroup -- F is streamed once (64-row tiles read it twice) while the
     // grid keeps as many workgroups as the 64 x 128 tiling
-    bool wide = C == 128 && !tall;
+    // (round 2, after the gates moved here: 128 x 64 measured fastest for every C % 128 == 0 -- 256 at 128^2 199 vs 220 us,
+    // 512 at 64^2 183 vs 192, 512 at 32^2 54 vs 58)
+    bool wide = C % 128 == 0;
     if (force) wide = force[0] == '3' && C % 128 == 0;
     static const bool k64 = [] { const char *e = getenv("ST3D_GRAM_BWD_K64"); return e && e[0] == '1'; }();
     if (force && force[0] == '4') {             // 64 rows x 256 pixels (1 KB row segments)

@@ -21,6 +21,14 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         out[f"{C}x{H}"] = round(e0.elapsed_time(e1) / 20 * 1e3, 1)
     print(json.dumps(out))
     sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "nsplit":       # the split count itself (ST3D_GRAM_NSPLIT), for grid-quantisation effects
+    for t in (0, 4, 5, 6, 8, 10, 12, 13, 16, 19, 21, 24, 26, 32, 42, 43, 48, 64):
+        env = dict(os.environ)
+        if t:
+            env["ST3D_GRAM_NSPLIT"] = str(t)
+        r = subprocess.run([sys.executable, __file__, "child"], env=env, capture_output=True, text=True)
+        print("nsplit", t or "default", r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-300:], flush=True)
+    sys.exit(0)
 for t in (0, 256, 512, 1024, 2048, 4096):
     env = dict(os.environ)
     if t:
