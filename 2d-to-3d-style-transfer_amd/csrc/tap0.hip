@@ -29,13 +29,14 @@ constexpr int kTaps = 27;                 // (ky, kx, image channel)
 // row of accumulator register v in lane half h of a 32x32 MFMA tile
 __host__ __device__ constexpr int acc_row(int v, int h) { return 8 * (v >> 2) + 4 * h + (v & 3); }
 
-// One wave = 64 consecutive pixels per iteration as two MFMA n-tiles (pixel p0 + 2 * lane31 + j), so every global access is
-// an 8-byte item per lane and a 256-byte run per row per wave; the four waves of a workgroup take adjacent runs.
-template <bool HAS_D, bool HAS_G>
-__global__ __launch_bounds__(256, 2) void conv1_bwd_gemm_kernel(const float *__restrict__ g, const float *__restrict__ F,
-                                                               const float *__restrict__ D, float coef,
-                                                               const float *__restrict__ wd, float *__restrict__ Y, int HW,
-                                                               int iters) {
+// One wave = 32 * J consecutive pixels per iteration as J MFMA n-tiles (pixel p0 + J * lane31 + j), so every global access is
+// a 4 * J-byte item per lane and a 128 * J-byte run per row per wave; the four waves of a workgroup take adjacent runs.
+// J = 2: 8-byte accesses at 2 waves per SIMD (256 VGPRs); J = 1: 4-byte accesses at 3 waves per SIMD.
+template <bool HAS_D, bool HAS_G, int J>
+__global__ __launch_bounds__(256, J == 2 ? 3 : 4) void conv1_bwd_gemm_kernel(const float *__restrict__ g, const float *__restrict__ F,
+                                                                         const float *__restrict__ D, float coef,
+                                                                         const float *__restrict__ wd, float *__restrict__ Y,
+                                                                         int HW, int iters) {
     __shared__ float A1s[HAS_D ? 2 * 32 * 64 : 64];   // [cout half][k step][lane]: coef * D[cout][k]
     __shared__ float A2s[32 * 64];                    // [k step][lane]: W'[(tap, i) = lane31][c]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -63,47 +64,53 @@ __global__ __launch_bounds__(256, 2) void conv1_bwd_gemm_kernel(const float *__r
         const_cast<float *>(HAS_G ? g + (size_t)n * 64 * HW : F), 0, 64u * rowb, 0x00020000);
     const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(Y + (size_t)n * kTaps * HW, 0, (unsigned)kTaps * rowb,
                                                                        0x00020000);
+    auto ld = [&](const __amdgpu_buffer_rsrc_t &r, unsigned vo, unsigned so, float (&dst)[J]) __attribute__((always_inline)) {
+        if (J == 2) {
+            const f32x2 t = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, vo, so, 0));
+            dst[0] = t[0]; dst[J - 1] = t[1];
+        } else {
+            dst[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, vo, so, 0));
+        }
+    };
     for (int it = 0; it < iters; ++it) {
-        const int px = ((blockIdx.x * iters + it) * 4 + wave) * 64 + 2 * l31;      // HW is even: px and px + 1 fall together
+        const int px = ((blockIdx.x * iters + it) * 4 + wave) * (32 * J) + J * l31;     // J = 2: HW is even, px and px + 1 fall together
         const unsigned voff = px < HW ? (unsigned)px * 4u + (unsigned)lhi * 4u * rowb : kOob;
-        f32x2 Fv[32];
-        f32x16 acc1[2][2];          // [pixel j][channel half]
+        float Fv[32][J];
+        f32x16 acc1[J][2];          // [pixel j][channel half]
+#pragma unroll
+        for (int s = 0; s < 32; ++s) ld(rF, voff, (unsigned)(32 * (s >> 4) + acc_row(s & 15, 0)) * rowb, Fv[s]);
 #pragma unroll
         for (int s = 0; s < 32; ++s) {
-            const unsigned so = (unsigned)(32 * (s >> 4) + acc_row(s & 15, 0)) * rowb;
-            Fv[s] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rF, voff, so, 0));
-        }
+            float t[J];
 #pragma unroll
-        for (int s = 0; s < 32; ++s) {
-            f32x2 t = {0.f, 0.f};
-            if (HAS_G) {
-                const unsigned so = (unsigned)(32 * (s >> 4) + acc_row(s & 15, 0)) * rowb;
-                t = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rG, voff, so, 0));
-            }
-            acc1[0][s >> 4][s & 15] = t[0];
-            acc1[1][s >> 4][s & 15] = t[1];
+            for (int j = 0; j < J; ++j) t[j] = 0.f;
+            if (HAS_G) ld(rG, voff, (unsigned)(32 * (s >> 4) + acc_row(s & 15, 0)) * rowb, t);
+#pragma unroll
+            for (int j = 0; j < J; ++j) acc1[j][s >> 4][s & 15] = t[j];
         }
+        __builtin_amdgcn_sched_barrier(0);      // keep the operand reads of the products below from being hoisted over the loads
         if (HAS_D) {
 #pragma unroll
             for (int s = 0; s < 32; ++s) {
                 const float a0 = A1s[s * 64 + lane], a1 = A1s[2048 + s * 64 + lane];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < J; ++j) {
                     acc1[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, Fv[s][j], acc1[j][0], 0, 0, 0);
                     acc1[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, Fv[s][j], acc1[j][1], 0, 0, 0);
                 }
             }
         }
-        f32x16 acc2[2];
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 acc2[J];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < J; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
 #pragma unroll
         for (int t = 0; t < 32; ++t) {
             const float a2 = A2s[t * 64 + lane];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < J; ++j) {
                 const float b = Fv[t][j] > 0.f ? acc1[j][t >> 4][t & 15] : 0.f;     // ReLU gate of relu1_1
                 acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b, acc2[j], 0, 0, 0);
             }
@@ -112,8 +119,13 @@ __global__ __launch_bounds__(256, 2) void conv1_bwd_gemm_kernel(const float *__r
 #pragma unroll
         for (int v = 0; v < 15; ++v) {
             const unsigned vo = (v >= 12 && lhi) ? kOob : voff;
-            const f32x2 o = {acc2[0][v], acc2[1][v]};
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rY, vo, (unsigned)acc_row(v, 0) * rowb, 0);
+            if (J == 2) {
+                const f32x2 o = {acc2[0][v], acc2[J - 1][v]};
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rY, vo, (unsigned)acc_row(v, 0) * rowb, 0);
+            } else {
+                const float o = acc2[0][v];      // (a bit_cast of the vector ELEMENT expression reads element 0)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rY, vo, (unsigned)acc_row(v, 0) * rowb, 0);
+            }
         }
     }
 }
@@ -160,11 +172,19 @@ extern "C" int st3d_conv1_bwd(const float *gy, const float *act, const float *D,
     hipStream_t s = st3d::as_stream(stream);
     const int HW = H * W;
     float *Y = reinterpret_cast<float *>(workspace);
-    const int iters = HW >= 4096 ? 4 : 1;               // 1024 (or 256) pixels per workgroup
-    const dim3 grid(st3d::cdiv(HW, 256 * iters), N);
-    if (D && gy) conv1_bwd_gemm_kernel<true, true><<<grid, 256, 0, s>>>(gy, act, D, coef, w_dgrad_packed, Y, HW, iters);
-    else if (D) conv1_bwd_gemm_kernel<true, false><<<grid, 256, 0, s>>>(gy, act, D, coef, w_dgrad_packed, Y, HW, iters);
-    else conv1_bwd_gemm_kernel<false, true><<<grid, 256, 0, s>>>(gy, act, D, coef, w_dgrad_packed, Y, HW, iters);
+    // ST3D_TAP0_J=1 / 2: pixels per lane (A/B runs)
+    static const int J = [] { const char *e = getenv("ST3D_TAP0_J"); return e && e[0] == '1' ? 1 : 2; }();
+    const int iters = HW >= 4096 ? 4 : 1;               // 128 * J * iters pixels per workgroup
+    const dim3 grid(st3d::cdiv(HW, 128 * J * iters), N);
+#define ST3D_TAP0_LAUNCH(JJ)                                                                                                  \
+    do {                                                                                                                      \
+        if (D && gy) conv1_bwd_gemm_kernel<true, true, JJ><<<grid, 256, 0, s>>>(gy, act, D, coef, w_dgrad_packed, Y, HW, iters);   \
+        else if (D) conv1_bwd_gemm_kernel<true, false, JJ><<<grid, 256, 0, s>>>(gy, act, D, coef, w_dgrad_packed, Y, HW, iters);   \
+        else conv1_bwd_gemm_kernel<false, true, JJ><<<grid, 256, 0, s>>>(gy, act, D, coef, w_dgrad_packed, Y, HW, iters);          \
+    } while (0)
+    if (J == 1) ST3D_TAP0_LAUNCH(1);
+    else ST3D_TAP0_LAUNCH(2);
+#undef ST3D_TAP0_LAUNCH
     ST3D_LAUNCH_CHECK();
     conv1_bwd_gather_kernel<<<dim3(st3d::cdiv(HW, 256), N), 256, 0, s>>>(Y, gx, H, W);
     ST3D_LAUNCH_CHECK();
