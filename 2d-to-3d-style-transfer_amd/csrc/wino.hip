@@ -494,7 +494,9 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
         } else {
             voff[i] = ok ? (unsigned)((ci * in_plane + (size_t)gy * W + gx0) * 4) : kOob;
         }
-        loff[i] = (e < ITEMS) ? (4 + ci * PS4 + r * PCP + 4 * l - 3) : -1;
+        // the 32 threads without a second item write theirs (zeros: voff is out of range) into the stage's trailing slack:
+        // no branch in lstore, so the stage loop is one basic block the scheduler can interleave
+        loff[i] = (e < ITEMS) ? (4 + ci * PS4 + r * PCP + 4 * l - 3) : (KS * PS4 + 4);
     }
     const unsigned img_bytes = (unsigned)((size_t)a.Cin * in_plane * 4);
     const unsigned stage_bytes = (unsigned)(KS * in_plane * 4);
@@ -533,7 +535,7 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
     auto lstore = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < IPT; ++i) {
-            if (loff[i] >= 0) {
+            {
                 float *dst = &sP[buf * P4_STAGE + loff[i]];
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
@@ -622,33 +624,49 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
         acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.h[0][ks][q], bv.v[ks][q], acc[0][q], 0, 0, 0);        \
         acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.h[1][ks][q], bv.v[ks][q], acc[1][q], 0, 0, 0);        \
     }
-    // one stage = 8 input channels = sub-chunks s0 (operands ready in ua / bcur) and s1; four bursts of 8 MFMAs with the
-    // wave's memory / LDS / VALU work between them (the co-resident workgroup's wave fills the pipe meanwhile)
+    // one stage = 8 input channels = sub-chunks s0 (operands ready in ua / bcur) and s1, as four quarters of 8 MFMAs.  Each
+    // quarter's memory / LDS / VALU work (which prepares LATER quarters) is INTERLEAVED with its MFMAs by
+    // sched_group_barrier -- one matrix instruction, then two or three of the others -- so the pipe stays fed even while the
+    // co-resident workgroup is between tiles and this wave is alone on its SIMD (round 2: 2 % over the ten VGG shapes, 3-4 %
+    // on the 8-/16-stage layers, against the same quarters issued as bursts of 8 MFMAs followed by the other work).  The
+    // stage loop is one basic block (lstore has no branch) so that the scheduler may do this.
+#define W4_ILV(mask, per)                                                             \
+    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \
+        __builtin_amdgcn_sched_group_barrier(mask, per, 0);                           \
+    }
     int pb = 0;
     for (int c = 0; c < nstages; ++c) {
         const int pb1 = (pb == 2) ? 0 : pb + 1, pb2 = (pb1 == 2) ? 0 : pb1 + 1;
-        W4_MFMA(ua, bcur, 0)
         __builtin_amdgcn_sched_barrier(0);
+        W4_MFMA(ua, bcur, 0)
         gload(min(c + 2, nstages - 1));
         uload(2 * c + 1, ub);
         pread(pb, 1, draw);
+        W4_ILV(0x120, 2)               // vector-memory reads | LDS reads
         __builtin_amdgcn_sched_barrier(0);
         W4_MFMA(ua, bcur, 1)
-        __builtin_amdgcn_sched_barrier(0);
         bcompute(draw, bnext);
+        W4_ILV(0x002, 2)               // VALU
         __builtin_amdgcn_sched_barrier(0);
         W4_MFMA(ub, bnext, 0)
-        __builtin_amdgcn_sched_barrier(0);
         uload(2 * c + 2, ua);
         pread(pb1, 0, draw);           // first sub-chunk of the NEXT stage (staged one barrier ago)
+        W4_ILV(0x120, 2)
         __builtin_amdgcn_sched_barrier(0);
         W4_MFMA(ub, bnext, 1)
-        __builtin_amdgcn_sched_barrier(0);
         bcompute(draw, bcur);
         lstore(pb2);
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, MODE == 0 ? 2 : 5, 0);      // the gates of MODE 1-3 are VALU work too
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                       // LDS writes
+        }
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         pb = pb1;
     }
+#undef W4_ILV
 #undef W4_MFMA
 
     if (DBG == 1) {                          // diagnostic: no epilogue (keeps the accumulators live with one store)
