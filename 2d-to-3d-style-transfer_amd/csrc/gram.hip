@@ -45,7 +45,10 @@ __device__ __forceinline__ float4 load4(const float *p, int remain, bool aligned
 // MT/NT: 32x32 MFMA tiles per wave along M/N.  BMODE 0: B is [N][K]; 1: B is [K][N].
 // DIAG 1: the only tile of a Gram forward whose C fits one tile (C = 64, 128) -- the B tile IS the A tile, fetched and
 // staged once (compile-time: the run-time test cost the multi-tile layers more than it saved them).
-template <int MT, int NT, int BMODE, int DIAG = 0, int KCH = 32>
+// FAST: every tile is whole and every access 16-byte aligned (the VGG shapes; checked by the launchers): no bounds code in
+// the loop, which then is one basic block per phase and gets an explicit interleaved schedule (one MFMA, one LDS read; the
+// next chunk's eight global loads under the first MFMAs) instead of whatever falls out of ~50 predicated branches.
+template <int MT, int NT, int BMODE, int DIAG = 0, int KCH = 32, bool FAST = false>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     constexpr int TM = 2 * MT * 32, TN = 2 * NT * 32;
     constexpr int LA = TM + 1;
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
                 if (g.accumulate) {
                     const int gm = m0 + wm * (MT * 32) + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                     const int gn = n0 + wn * (NT * 32) + q * 32 + l31;
-                    if (gm < g.M && gn < g.N) v = Cb[(size_t)gm * g.ldc + gn];
+                    if (FAST || (gm < g.M && gn < g.N)) v = Cb[(size_t)gm * g.ldc + gn];
                 }
                 acc[m][q][r] = v;
             }
@@ -109,8 +112,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         for (int i = 0; i < A4; ++i) {       // A tile: TM rows x 32 k, 8 float4 per row
             const int e = tid + i * 256, row = e / (KCH / 4), kq = (e % (KCH / 4)) * 4;
             const int gm = m0 + row, gk = k0 + kq;
-            av[i] = (gm < g.M) ? load4(Ab + (size_t)gm * g.lda + gk, kend - gk, a_al && ((gk & 3) == 0))
-                               : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (FAST) av[i] = *reinterpret_cast<const float4 *>(Ab + (size_t)gm * g.lda + gk);
+            else av[i] = (gm < g.M) ? load4(Ab + (size_t)gm * g.lda + gk, kend - gk, a_al && ((gk & 3) == 0))
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         if (diag) return;
 #pragma unroll
@@ -119,13 +123,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
             if (BMODE == 0) {                // [N][K]: TN rows x 32 k
                 const int row = e / (KCH / 4), kq = (e % (KCH / 4)) * 4;
                 const int gn = n0 + row, gk = k0 + kq;
-                bv[i] = (gn < g.N) ? load4(Bb + (size_t)gn * g.ldb + gk, kend - gk, b_al && ((gk & 3) == 0))
-                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (FAST) bv[i] = *reinterpret_cast<const float4 *>(Bb + (size_t)gn * g.ldb + gk);
+                else bv[i] = (gn < g.N) ? load4(Bb + (size_t)gn * g.ldb + gk, kend - gk, b_al && ((gk & 3) == 0))
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
             } else {                         // [K][N]: 32 k rows x TN cols
                 const int kr = e / (TN / 4), nq = (e - kr * (TN / 4)) * 4;
                 const int gk = k0 + kr, gn = n0 + nq;
-                bv[i] = (gk < kend) ? load4(Bb + (size_t)gk * g.ldb + gn, g.N - gn, b_al && ((gn & 3) == 0))
-                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (FAST) bv[i] = *reinterpret_cast<const float4 *>(Bb + (size_t)gk * g.ldb + gn);
+                else bv[i] = (gk < kend) ? load4(Bb + (size_t)gk * g.ldb + gn, g.N - gn, b_al && ((gn & 3) == 0))
+                                         : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
     };
@@ -190,6 +196,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
                 for (int q = 0; q < NT; ++q)
                     acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bb[q], acc[m][q], 0, 0, 0);
         }
+        if (FAST) {
+            // schedule of the region since the barrier: one MFMA, then one LDS read (operands of a later k-step) and, while
+            // they last, one of the next chunk's global loads
+#pragma unroll
+            for (int i = 0; i < (KCH / 2) * MT * NT; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 
 #pragma unroll
@@ -197,11 +214,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int gm = m0 + wm * (MT * 32) + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-            if (gm >= g.M) continue;
+            if (!FAST && gm >= g.M) continue;
 #pragma unroll
             for (int q = 0; q < NT; ++q) {
                 const int gn = n0 + wn * (NT * 32) + q * 32 + l31;
-                if (gn < g.N) {
+                if (FAST || gn < g.N) {
                     Cb[(size_t)gm * g.ldc + gn] = (BMODE == 1 && !((gmask[m][q] >> r) & 1u)) ? 0.f : acc[m][q][r];
                 }
             }
@@ -297,10 +314,13 @@ extern "C" int st3d_gram_fwd(const float *feat, int B, int C, int HW, void *work
     const int TM = (C % 128 == 0) ? 128 : 64;
     g.tiles_m = g.tiles_n = st3d::cdiv(C, TM);
     dim3 grid(g.tiles_n * (g.tiles_n + 1) / 2, g.nsplit, B);
+    // whole tiles, whole 32-pixel chunks in every split, 16-byte aligned rows: the branch-free instantiation
+    static const bool allow_fast = [] { const char *e = getenv("ST3D_GRAM_FAST"); return !(e && e[0] == '0'); }();
+    const bool fast = allow_fast && C % TM == 0 && HW % 32 == 0 && g.kper % 32 == 0 && (((uintptr_t)feat) & 15) == 0;
     if (g.tiles_n == 1) {           // one (diagonal) tile: A and B tiles coincide
-        if (TM == 128) gemm_kernel<2, 2, 0, 1><<<grid, 256, 0, s>>>(g);
-        else gemm_kernel<1, 1, 0, 1><<<grid, 256, 0, s>>>(g);
-    } else if (TM == 128) gemm_kernel<2, 2, 0><<<grid, 256, 0, s>>>(g);
+        if (TM == 128) { if (fast) gemm_kernel<2, 2, 0, 1, 32, true><<<grid, 256, 0, s>>>(g); else gemm_kernel<2, 2, 0, 1><<<grid, 256, 0, s>>>(g); }
+        else { if (fast) gemm_kernel<1, 1, 0, 1, 32, true><<<grid, 256, 0, s>>>(g); else gemm_kernel<1, 1, 0, 1><<<grid, 256, 0, s>>>(g); }
+    } else if (TM == 128) { if (fast) gemm_kernel<2, 2, 0, 0, 32, true><<<grid, 256, 0, s>>>(g); else gemm_kernel<2, 2, 0><<<grid, 256, 0, s>>>(g); }
     else gemm_kernel<1, 1, 0><<<grid, 256, 0, s>>>(g);
     ST3D_LAUNCH_CHECK();
     gram_reduce_kernel<<<dim3(st3d::cdiv((long)C * C, 64), B), 256, 0, s>>>(g.C, g.nsplit, C, TM, g.sSplit, g.sC, gram);
@@ -354,6 +374,7 @@ static int gram_bwd_launch(const float *D, const float *feat, int B, int C, int 
         ST3D_LAUNCH_CHECK();
         return ST3D_OK;
     }
+    // (the branch-free FAST instantiation is forward-only: measured 3-6 % SLOWER on every backward shape)
     if (wide) {
         g.tiles_m = C / 128; g.tiles_n = st3d::cdiv(HW, 64);
         if (k64) gemm_kernel<2, 1, 1, 0, 64><<<dim3(g.tiles_m * g.tiles_n, 1, B), 256, 0, s>>>(g);

@@ -635,6 +635,10 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \
         __builtin_amdgcn_sched_group_barrier(mask, per, 0);                           \
     }
+#ifndef ST3D_WINO_SCHED
+#define ST3D_WINO_SCHED 0
+#endif
+#if ST3D_WINO_SCHED == 0
     int pb = 0;
     for (int c = 0; c < nstages; ++c) {
         const int pb1 = (pb == 2) ? 0 : pb + 1, pb2 = (pb1 == 2) ? 0 : pb1 + 1;
@@ -666,6 +670,99 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
         __syncthreads();
         pb = pb1;
     }
+#elif ST3D_WINO_SCHED == 1      // LDS reads first in the memory quarters
+    int pb = 0;
+    for (int c = 0; c < nstages; ++c) {
+        const int pb1 = (pb == 2) ? 0 : pb + 1, pb2 = (pb1 == 2) ? 0 : pb1 + 1;
+        __builtin_amdgcn_sched_barrier(0);
+        W4_MFMA(ua, bcur, 0)
+        gload(min(c + 2, nstages - 1));
+        uload(2 * c + 1, ub);
+        pread(pb, 1, draw);
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 3, 0); }
+        __builtin_amdgcn_sched_barrier(0);
+        W4_MFMA(ua, bcur, 1)
+        bcompute(draw, bnext);
+        W4_ILV(0x002, 2)
+        __builtin_amdgcn_sched_barrier(0);
+        W4_MFMA(ub, bnext, 0)
+        uload(2 * c + 2, ua);
+        pread(pb1, 0, draw);
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 2, 0); }
+        __builtin_amdgcn_sched_barrier(0);
+        W4_MFMA(ub, bnext, 1)
+        bcompute(draw, bcur);
+        lstore(pb2);
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, MODE == 0 ? 2 : 5, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        pb = pb1;
+    }
+#elif ST3D_WINO_SCHED == 2      // two regions of 16 MFMAs: the VALU of a half may start under the memory quarter's MFMAs
+    int pb = 0;
+    for (int c = 0; c < nstages; ++c) {
+        const int pb1 = (pb == 2) ? 0 : pb + 1, pb2 = (pb1 == 2) ? 0 : pb1 + 1;
+        __builtin_amdgcn_sched_barrier(0);
+        W4_MFMA(ua, bcur, 0)
+        gload(min(c + 2, nstages - 1));
+        uload(2 * c + 1, ub);
+        pread(pb, 1, draw);
+        W4_MFMA(ua, bcur, 1)
+        bcompute(draw, bnext);
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+        _Pragma("unroll") for (int i_ = 0; i_ < 12; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); }
+        __builtin_amdgcn_sched_barrier(0);
+        W4_MFMA(ub, bnext, 0)
+        uload(2 * c + 2, ua);
+        pread(pb1, 0, draw);
+        W4_MFMA(ub, bnext, 1)
+        bcompute(draw, bcur);
+        lstore(pb2);
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+        _Pragma("unroll") for (int i_ = 0; i_ < 12; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, MODE == 0 ? 2 : 4, 0); __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        pb = pb1;
+    }
+#elif ST3D_WINO_SCHED == 3      // as 0 with three other instructions per MFMA
+    int pb = 0;
+    for (int c = 0; c < nstages; ++c) {
+        const int pb1 = (pb == 2) ? 0 : pb + 1, pb2 = (pb1 == 2) ? 0 : pb1 + 1;
+        __builtin_amdgcn_sched_barrier(0);
+        W4_MFMA(ua, bcur, 0)
+        gload(min(c + 2, nstages - 1));
+        uload(2 * c + 1, ub);
+        pread(pb, 1, draw);
+        W4_ILV(0x120, 3)
+        __builtin_amdgcn_sched_barrier(0);
+        W4_MFMA(ua, bcur, 1)
+        bcompute(draw, bnext);
+        W4_ILV(0x002, 3)
+        __builtin_amdgcn_sched_barrier(0);
+        W4_MFMA(ub, bnext, 0)
+        uload(2 * c + 2, ua);
+        pread(pb1, 0, draw);
+        W4_ILV(0x120, 3)
+        __builtin_amdgcn_sched_barrier(0);
+        W4_MFMA(ub, bnext, 1)
+        bcompute(draw, bcur);
+        lstore(pb2);
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, MODE == 0 ? 3 : 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        pb = pb1;
+    }
+#endif
 #undef W4_ILV
 #undef W4_MFMA
 
