@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
             for (int i = 0; i < (KCH / 2) * MT * NT; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, (MT + NT + MT * NT - 1) / (MT * NT), 0);      // LDS reads per MFMA, rounded up
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -374,7 +374,8 @@ static int gram_bwd_launch(const float *D, const float *feat, int B, int C, int 
         ST3D_LAUNCH_CHECK();
         return ST3D_OK;
     }
-    // (the branch-free FAST instantiation is forward-only: measured 3-6 % SLOWER on every backward shape)
+    // (the branch-free FAST instantiation is forward-only: measured 3-8 % SLOWER on the backward shapes, with the explicit
+    // schedule -- one or two LDS reads per MFMA -- and without it)
     if (wide) {
         g.tiles_m = C / 128; g.tiles_n = st3d::cdiv(HW, 64);
         if (k64) gemm_kernel<2, 1, 1, 0, 64><<<dim3(g.tiles_m * g.tiles_n, 1, B), 256, 0, s>>>(g);
