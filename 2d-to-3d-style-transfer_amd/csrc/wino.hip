@@ -626,7 +626,7 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
     }
     // one stage = 8 input channels = sub-chunks s0 (operands ready in ua / bcur) and s1, as four quarters of 8 MFMAs.  Each
     // quarter's memory / LDS / VALU work (which prepares LATER quarters) is INTERLEAVED with its MFMAs by
-    // sched_group_barrier -- one matrix instruction, then two or three of the others -- so the pipe stays fed even while the
+    // sched_group_barrier -- one matrix instruction, then one to three of the others -- so the pipe stays fed even while the
     // co-resident workgroup is between tiles and this wave is alone on its SIMD (round 2: 2 % over the ten VGG shapes, 3-4 %
     // on the 8-/16-stage layers, against the same quarters issued as bursts of 8 MFMAs followed by the other work).  The
     // stage loop is one basic block (lstore has no branch) so that the scheduler may do this.
@@ -635,10 +635,12 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \
         __builtin_amdgcn_sched_group_barrier(mask, per, 0);                           \
     }
+    // ST3D_WINO_SCHED (compile-time, tools/wino_sched_ab.sh): 0 = one memory instruction per MFMA in the two memory quarters
+    // (default), 1 = two.  Measured and dropped: three per MFMA (-1 %), halves of 16 MFMAs as one region with the VALU work
+    // spread over them (-2 %), LDS reads before the global loads (=), s_setprio around the stage (=).
 #ifndef ST3D_WINO_SCHED
 #define ST3D_WINO_SCHED 0
 #endif
-#if ST3D_WINO_SCHED == 0
     int pb = 0;
     for (int c = 0; c < nstages; ++c) {
         const int pb1 = (pb == 2) ? 0 : pb + 1, pb2 = (pb1 == 2) ? 0 : pb1 + 1;
@@ -647,7 +649,7 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
         gload(min(c + 2, nstages - 1));
         uload(2 * c + 1, ub);
         pread(pb, 1, draw);
-        W4_ILV(0x120, 2)               // vector-memory reads | LDS reads
+        W4_ILV(0x120, ST3D_WINO_SCHED == 0 ? 1 : 2)               // vector-memory reads | LDS reads
         __builtin_amdgcn_sched_barrier(0);
         W4_MFMA(ua, bcur, 1)
         bcompute(draw, bnext);
@@ -656,7 +658,7 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
         W4_MFMA(ub, bnext, 0)
         uload(2 * c + 2, ua);
         pread(pb1, 0, draw);           // first sub-chunk of the NEXT stage (staged one barrier ago)
-        W4_ILV(0x120, 2)
+        W4_ILV(0x120, ST3D_WINO_SCHED == 0 ? 1 : 2)
         __builtin_amdgcn_sched_barrier(0);
         W4_MFMA(ub, bnext, 1)
         bcompute(draw, bcur);
@@ -670,99 +672,6 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
         __syncthreads();
         pb = pb1;
     }
-#elif ST3D_WINO_SCHED == 1      // LDS reads first in the memory quarters
-    int pb = 0;
-    for (int c = 0; c < nstages; ++c) {
-        const int pb1 = (pb == 2) ? 0 : pb + 1, pb2 = (pb1 == 2) ? 0 : pb1 + 1;
-        __builtin_amdgcn_sched_barrier(0);
-        W4_MFMA(ua, bcur, 0)
-        gload(min(c + 2, nstages - 1));
-        uload(2 * c + 1, ub);
-        pread(pb, 1, draw);
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 3, 0); }
-        __builtin_amdgcn_sched_barrier(0);
-        W4_MFMA(ua, bcur, 1)
-        bcompute(draw, bnext);
-        W4_ILV(0x002, 2)
-        __builtin_amdgcn_sched_barrier(0);
-        W4_MFMA(ub, bnext, 0)
-        uload(2 * c + 2, ua);
-        pread(pb1, 0, draw);
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 2, 0); }
-        __builtin_amdgcn_sched_barrier(0);
-        W4_MFMA(ub, bnext, 1)
-        bcompute(draw, bcur);
-        lstore(pb2);
-        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, MODE == 0 ? 2 : 5, 0);
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        pb = pb1;
-    }
-#elif ST3D_WINO_SCHED == 2      // two regions of 16 MFMAs: the VALU of a half may start under the memory quarter's MFMAs
-    int pb = 0;
-    for (int c = 0; c < nstages; ++c) {
-        const int pb1 = (pb == 2) ? 0 : pb + 1, pb2 = (pb1 == 2) ? 0 : pb1 + 1;
-        __builtin_amdgcn_sched_barrier(0);
-        W4_MFMA(ua, bcur, 0)
-        gload(min(c + 2, nstages - 1));
-        uload(2 * c + 1, ub);
-        pread(pb, 1, draw);
-        W4_MFMA(ua, bcur, 1)
-        bcompute(draw, bnext);
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
-        _Pragma("unroll") for (int i_ = 0; i_ < 12; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); }
-        __builtin_amdgcn_sched_barrier(0);
-        W4_MFMA(ub, bnext, 0)
-        uload(2 * c + 2, ua);
-        pread(pb1, 0, draw);
-        W4_MFMA(ub, bnext, 1)
-        bcompute(draw, bcur);
-        lstore(pb2);
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
-        _Pragma("unroll") for (int i_ = 0; i_ < 12; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, MODE == 0 ? 2 : 4, 0); __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); }
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        pb = pb1;
-    }
-#elif ST3D_WINO_SCHED == 3      // as 0 with three other instructions per MFMA
-    int pb = 0;
-    for (int c = 0; c < nstages; ++c) {
-        const int pb1 = (pb == 2) ? 0 : pb + 1, pb2 = (pb1 == 2) ? 0 : pb1 + 1;
-        __builtin_amdgcn_sched_barrier(0);
-        W4_MFMA(ua, bcur, 0)
-        gload(min(c + 2, nstages - 1));
-        uload(2 * c + 1, ub);
-        pread(pb, 1, draw);
-        W4_ILV(0x120, 3)
-        __builtin_amdgcn_sched_barrier(0);
-        W4_MFMA(ua, bcur, 1)
-        bcompute(draw, bnext);
-        W4_ILV(0x002, 3)
-        __builtin_amdgcn_sched_barrier(0);
-        W4_MFMA(ub, bnext, 0)
-        uload(2 * c + 2, ua);
-        pread(pb1, 0, draw);
-        W4_ILV(0x120, 3)
-        __builtin_amdgcn_sched_barrier(0);
-        W4_MFMA(ub, bnext, 1)
-        bcompute(draw, bcur);
-        lstore(pb2);
-        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, MODE == 0 ? 3 : 6, 0);
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        pb = pb1;
-    }
-#endif
 #undef W4_ILV
 #undef W4_MFMA
 
