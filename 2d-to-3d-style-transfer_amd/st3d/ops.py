@@ -45,15 +45,31 @@ def project_verts(verts, R, T):
 # ---- near-plane watch of the specialised K = 1 rasteriser.  PyTorch3D clips every mesh at z_clip_value = znear / 2 before
 # rasterising; the K = 1 / blur 0 kernels do not clip (for the reference's cameras nothing comes nearer than 0.78), so they
 # raise a device flag when a rasterised face has a vertex nearer than z_clip.  The flag travels to pinned host memory
-# without blocking and is looked at when a later call finds its copy complete (or by check_near_plane(block=True)): a mesh
-# that does reach the plane fails loudly, one call late, instead of being rendered differently from PyTorch3D.
+# without blocking and is looked at when a later call finds its copy complete (or by check_near_plane(block=True)).
+# Policy (ST3D_NEAR_PLANE, default "clip"): from then on every render of the process goes through the general kernels,
+# which clip exactly like PyTorch3D (st3d.render.render_views asks near_plane_triggered()), with one warning -- a vertex
+# optimisation that drives the mesh into the near plane (bob, 'both', lr 0.01: after ~80 steps) keeps running like the
+# reference does; the one or two frames rendered before the flag arrived were rendered unclipped.  "raise": fail loudly.
 _NEAR_PENDING = []
+_NEAR_TRIGGERED = False
+NEAR_PLANE_POLICY = os.environ.get("ST3D_NEAR_PLANE", "clip")
 NEAR_PLANE_MESSAGE = ("a rasterised face has a vertex nearer than z_clip_value (PyTorch3D clips meshes at znear / 2 = 0.5); the "
                       "specialised K = 1 kernels do not clip -- construct RasterizationSettings(z_clip_value=0.5) to render "
                       "through the general kernels, which do")
 
 
+def near_plane_triggered():
+    return _NEAR_TRIGGERED
+
+
+def reset_near_plane():
+    global _NEAR_TRIGGERED
+    _NEAR_TRIGGERED = False
+    _NEAR_PENDING.clear()
+
+
 def check_near_plane(block=False):
+    global _NEAR_TRIGGERED
     while _NEAR_PENDING:
         host, ev = _NEAR_PENDING[0]
         if block:
@@ -63,7 +79,13 @@ def check_near_plane(block=False):
         _NEAR_PENDING.pop(0)
         if int(host[0]) != 0:
             _NEAR_PENDING.clear()
-            raise RuntimeError(NEAR_PLANE_MESSAGE)
+            if NEAR_PLANE_POLICY == "raise":
+                raise RuntimeError(NEAR_PLANE_MESSAGE)
+            if not _NEAR_TRIGGERED:
+                import warnings
+                warnings.warn("st3d: the mesh reached the near clipping plane (z < znear / 2); rendering continues on the general "
+                              "kernels, which clip like PyTorch3D (ST3D_NEAR_PLANE=raise turns this into an error)")
+            _NEAR_TRIGGERED = True
 
 
 def raster_fwd(verts_ndc, faces_i32, S, z_clip=None):

@@ -388,6 +388,10 @@ def render_views(meshes, R, T, image_size, raster_settings=None, blend_params=No
     tex = meshes.textures
     dev = meshes.device
     rs, bp = raster_settings, blend_params
+    if uses_hard_path(rs, bp) and ops.near_plane_triggered():
+        # the specialised kernels do not clip and this process has seen a mesh at the near plane: same settings on the
+        # general kernels with PyTorch3D's default clipping depth (ops.check_near_plane)
+        rs = RasterizationSettings(image_size=image_size, z_clip_value=RasterizationSettings.Z_CLIP_DEFAULT)
     if uses_hard_path(rs, bp):
         # K=1, blur 0: the blend weight cancels and the pixel is the sampled texel itself
         return _RenderFn.apply(meshes.verts_packed(), tex.maps_padded(), meshes.faces_i32(), tex.verts_uvs_padded(),

@@ -628,11 +628,12 @@ def test_soft_raster_backward_through_clipped_faces_matches_fp64_autograd(dev, o
             assert rel <= 1e-4, (name, persp, K, rel)
 
 
-def test_renderer_near_plane_policy(dev, cow):
+def test_renderer_near_plane_policy(dev, cow, monkeypatch):
     """PyTorch3D clips at z_clip_value = znear / 2.  Through MeshRenderer: an explicit z_clip_value renders on the general
     kernels WITH clipping (pixels against the oracle's clipped fragments, gradients flow); the specialised K = 1 path does
-    not clip and must say so -- a render whose mesh reaches the plane raises at the next check instead of silently
-    differing; the reference's own views (nothing nearer than 0.78) never trip the watch."""
+    not clip and must say so -- a render whose mesh reaches the plane is noticed at the next check: by default the process
+    switches to the clipping kernels (one warning), under ST3D_NEAR_PLANE=raise it fails; the reference's own views
+    (nothing nearer than 0.78) never trip the watch."""
     import utils as U
     from oracle import render_ref as rr
     from st3d import ops as O
@@ -666,12 +667,27 @@ def test_renderer_near_plane_policy(dev, cow):
         b, _ = clipping.render(mesh, far)
     np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=2e-6)
     O.check_near_plane(block=True)
-    # near view on the specialised path: loud
+    # near view on the specialised path, policy "raise": loud
+    monkeypatch.setattr(O, "NEAR_PLANE_POLICY", "raise")
     with torch.no_grad():
         plain.render(mesh, near)
     with pytest.raises(RuntimeError, match="z_clip_value"):
         O.check_near_plane(block=True)
     O.check_near_plane(block=True)                      # the failure is reported once
+    # default policy "clip": one warning, and from then on the SAME renderer object renders through the clipping kernels
+    monkeypatch.setattr(O, "NEAR_PLANE_POLICY", "clip")
+    try:
+        with torch.no_grad():
+            plain.render(mesh, near)                    # unclipped frame; raises the flag
+            with pytest.warns(UserWarning, match="near clipping plane"):
+                O.check_near_plane(block=True)
+            assert O.near_plane_triggered()
+            c, ccov = plain.render(mesh, near)
+        np.testing.assert_array_equal((ccov[0, 0] > 0).cpu().numpy(), frag[0][..., 0] >= 0)
+        np.testing.assert_allclose(c[0].cpu().numpy(), ref_rgb, atol=3e-6)
+    finally:
+        O.reset_near_plane()
+    assert not O.near_plane_triggered()
 
 
 def test_renderer_routes_non_default_raster_flags_to_the_general_kernels(dev, cow):
