@@ -532,28 +532,41 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
             }
         }
     };
-    auto lstore = [&](int buf) __attribute__((always_inline)) {
+    // lgate: the staged items' values after their gate (ReLU / pool routing) -- VALU work; lwrite: into the LDS ring.  Kept
+    // apart so the stage loop can place them in different quarters (lstore = both, for the prologue).
+    struct Vals { float v[IPT][4]; };
+    auto lgate = [&](Vals &o) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < IPT; ++i) {
-            {
-                float *dst = &sP[buf * P4_STAGE + loff[i]];
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    float v;
-                    if (MODE == 0) v = xv[i][jj];
-                    if (MODE == 1) v = (xa[i][jj] > 0.f) ? xv[i][jj] : 0.f;
-                    if (MODE == 2) {
-                        const unsigned ib = (xi[i] >> (8 * (jj >> 1))) & 0xffu;
-                        v = (xp[i][jj >> 1] > 0.f && ib == (rowbit[i] | (jj & 1))) ? xg[i][jj >> 1] : 0.f;
-                    }
-                    if (MODE == 3) {
-                        const unsigned ib = (xi[i] >> (8 * (jj >> 1))) & 0xffu;
-                        v = (ib == (rowbit[i] | (jj & 1))) ? xg[i][jj >> 1] : 0.f;
-                    }
-                    dst[jj] = v;
+            for (int jj = 0; jj < 4; ++jj) {
+                float v;
+                if (MODE == 0) v = xv[i][jj];
+                if (MODE == 1) v = (xa[i][jj] > 0.f) ? xv[i][jj] : 0.f;
+                if (MODE == 2) {
+                    const unsigned ib = (xi[i] >> (8 * (jj >> 1))) & 0xffu;
+                    v = (xp[i][jj >> 1] > 0.f && ib == (rowbit[i] | (jj & 1))) ? xg[i][jj >> 1] : 0.f;
                 }
+                if (MODE == 3) {
+                    const unsigned ib = (xi[i] >> (8 * (jj >> 1))) & 0xffu;
+                    v = (ib == (rowbit[i] | (jj & 1))) ? xg[i][jj >> 1] : 0.f;
+                }
+                o.v[i][jj] = v;
             }
         }
+    };
+    auto lwrite = [&](int buf, const Vals &o) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) {
+            float *dst = &sP[buf * P4_STAGE + loff[i]];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) dst[jj] = o.v[i][jj];
+        }
+    };
+    auto lstore = [&](int buf) __attribute__((always_inline)) {
+        Vals o;
+        lgate(o);
+        lwrite(buf, o);
     };
 
     // B operands: row transform of the wave's row a (t = d[r1] + sg * d[r2]), then the column transform per b
@@ -658,14 +671,20 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
         W4_MFMA(ub, bnext, 0)
         uload(2 * c + 2, ua);
         pread(pb1, 0, draw);           // first sub-chunk of the NEXT stage (staged one barrier ago)
-        W4_ILV(0x120, ST3D_WINO_SCHED == 0 ? 1 : 2)
+        Vals staged;
+        lgate(staged);                 // the gates of MODE 1-3 (VALU) ride in this quarter, the LDS writes in the next
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x120, ST3D_WINO_SCHED == 0 ? 1 : 2, 0);
+            if (MODE != 0) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
         W4_MFMA(ub, bnext, 1)
         bcompute(draw, bcur);
-        lstore(pb2);
+        lwrite(pb2, staged);
         _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, MODE == 0 ? 2 : 5, 0);      // the gates of MODE 1-3 are VALU work too
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
             __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                       // LDS writes
         }
         __builtin_amdgcn_sched_barrier(0);
