@@ -650,7 +650,8 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
     }
     // ST3D_WINO_SCHED (compile-time, tools/wino_sched_ab.sh): 0 = one memory instruction per MFMA in the two memory quarters
     // (default), 1 = two.  Measured and dropped: three per MFMA (-1 %), halves of 16 MFMAs as one region with the VALU work
-    // spread over them (-2 %), LDS reads before the global loads (=), s_setprio around the stage (=).
+    // spread over them (-2 %), LDS reads before the global loads (=), s_setprio around the stage (=), the stage's barrier
+    // moved behind the first quarter's MFMAs instead of the stage end (legal for the 3-deep ring; -0.5 %).
 #ifndef ST3D_WINO_SCHED
 #define ST3D_WINO_SCHED 0
 #endif
