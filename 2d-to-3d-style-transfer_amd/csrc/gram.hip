@@ -12,6 +12,8 @@
 // fp32 ridge for C = 64 where F (the largest activation) is streamed exactly once.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -72,6 +74,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     }
     const int split = blockIdx.y, b = blockIdx.z;
     const int m0 = ti * TM, n0 = tj * TN;
+    // a diagonal tile of the multi-tile Gram forward: the lower-left wave would compute the mirror image of the upper-right
+    // one -- it sits the MFMAs out and the reduce mirrors at wave-tile granularity (FAST launches only)
+    const bool mirror_wave = FAST && BMODE == 0 && !DIAG && g.tri && ti == tj && wm > wn;
     static_assert(!DIAG || (BMODE == 0 && MT == NT), "DIAG is the single-tile Gram forward");
     constexpr bool diag = DIAG != 0;
     const int kbeg = split * g.kper, kend = min(g.K, kbeg + g.kper);
@@ -183,6 +188,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         }
         const float *pa = As + lhi * LA + wm * (MT * 32) + l31;
         const float *pb = (diag ? As : Bs) + lhi * LB + wn * (NT * 32) + l31;      // (LA == LB when TM == TN)
+        if (mirror_wave) continue;           // (still stages its share of the tiles and meets the barriers)
 #pragma unroll
         for (int kk = 0; kk < KCH / 2; ++kk) {
             float a[MT], bb[NT];
@@ -209,6 +215,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         }
     }
 
+    if (mirror_wave) return;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -223,6 +230,94 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
                 }
             }
         }
+}
+
+// Gram forward of the single-tile layers (C = 64: NB = 2, C = 128: NB = 4 blocks of 32 channels), whole aligned shapes only.
+// The 4 waves of gemm_kernel<.., DIAG> tile the full C x C output, so a quarter (C = 64) to three eighths (C = 128) of
+// their MFMAs compute the mirror image of another wave's block.  Here only the NB (NB + 1) / 2 blocks on or above the
+// diagonal exist and the waves split the K chunk instead: C = 64 -- every wave owns all 3 blocks over a quarter of the
+// chunk's k-steps; C = 128 -- two block groups of 5 x two k-groups.  Each k-group writes its own slab (the ordered
+// reduce sums KG x nsplit of them and mirrors at block granularity), so nothing is exchanged between waves.  One LDS
+// value serves as row operand and as column operand (the tile is its own transpose partner).
+template <int NB>
+__global__ __launch_bounds__(256, 2) void gram_diag_kernel(const GemmArgs g) {
+    constexpr int TM = 32 * NB, LA = TM + 1, KCH = 32;
+    constexpr int KG = NB == 2 ? 4 : 2;                 // k-groups
+    constexpr int NBLK = NB == 2 ? 3 : 5;               // blocks per wave
+    constexpr int A4 = TM * KCH / 4 / 256;
+    __shared__ __attribute__((aligned(16))) float As[KCH * LA];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int kg = NB == 2 ? wave : (wave >> 1), bg = NB == 2 ? 0 : (wave & 1);
+    const int split = blockIdx.y, b = blockIdx.z;
+    const int kbeg = split * g.kper, kend = min(g.K, kbeg + g.kper);
+    const float *Ab = g.A + b * g.sA;
+    float *Cb = g.C + b * g.sC + (size_t)(split * KG + kg) * g.sSplit;
+    // block list (row block, column block) of this wave's block group
+    constexpr int BI[2][5] = {{0, 0, 0, 0, 1}, {1, 1, 2, 2, 3}};
+    constexpr int BJ[2][5] = {{0, 1, 2, 3, 1}, {2, 3, 2, 3, 3}};
+    constexpr int CI[3] = {0, 0, 1}, CJ[3] = {0, 1, 1};
+
+    f32x16 acc[NBLK];
+#pragma unroll
+    for (int i = 0; i < NBLK; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float4 av[A4];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < A4; ++i) {
+            const int e = tid + i * 256, row = e / (KCH / 4), kq = (e % (KCH / 4)) * 4;
+            av[i] = *reinterpret_cast<const float4 *>(Ab + (size_t)row * g.lda + k0 + kq);
+        }
+    };
+    if (kbeg < kend) load_tile(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += KCH) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < A4; ++i) {
+            const int e = tid + i * 256, row = e / (KCH / 4), kq = (e % (KCH / 4)) * 4;
+            As[(kq + 0) * LA + row] = av[i].x; As[(kq + 1) * LA + row] = av[i].y;
+            As[(kq + 2) * LA + row] = av[i].z; As[(kq + 3) * LA + row] = av[i].w;
+        }
+        __syncthreads();
+        if (k0 + KCH < kend) load_tile(k0 + KCH);
+        const float *pa = As + lhi * LA + l31;
+        // (the block group is wave-uniform: two straight-line copies of the loop with compile-time block indices)
+        auto mfmas = [&](auto BGc) __attribute__((always_inline)) {
+            constexpr int BG = decltype(BGc)::value;
+#pragma unroll
+            for (int kk = 0; kk < KCH / 2 / KG; ++kk) {
+                const int krow = 2 * (kg * (KCH / 2 / KG) + kk);
+                float v[NB];
+#pragma unroll
+                for (int x = 0; x < NB; ++x) v[x] = pa[krow * LA + x * 32];
+#pragma unroll
+                for (int i = 0; i < NBLK; ++i) {
+                    const int bi = NB == 2 ? CI[i] : BI[BG][i];
+                    const int bj = NB == 2 ? CJ[i] : BJ[BG][i];
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[bi], v[bj], acc[i], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < (KCH / 2 / KG) * NBLK; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if (bg == 0) mfmas(std::integral_constant<int, 0>{});
+        else mfmas(std::integral_constant<int, 1>{});
+    }
+#pragma unroll
+    for (int i = 0; i < NBLK; ++i) {
+        const int bi = NB == 2 ? CI[i] : (bg == 0 ? BI[0][i] : BI[1][i]);
+        const int bj = NB == 2 ? CJ[i] : (bg == 0 ? BJ[0][i] : BJ[1][i]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            Cb[(size_t)(bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * g.ldc + bj * 32 + l31] = acc[i][r];
+    }
 }
 
 // G[b][i][j] = sum over the split slabs of the element, in a FIXED tree (4 interleaved partial sums per element, each
@@ -291,10 +386,13 @@ int gram_split(int B, int C, int HW, int *kper) {
 
 }  // namespace
 
+// the single-tile layers may run gram_diag_kernel, which writes KG slabs per split (4 for C = 64, 2 for C = 128)
+static int gram_kgroups(int C) { return C == 64 ? 4 : (C == 128 ? 2 : 1); }
+
 extern "C" size_t st3d_gram_workspace_bytes(int B, int C, int HW) {
     int kper;
     const int ns = gram_split(B, C, HW, &kper);
-    return (size_t)B * ns * C * C * sizeof(float);
+    return (size_t)B * ns * gram_kgroups(C) * C * C * sizeof(float);
 }
 
 extern "C" int st3d_gram_fwd(const float *feat, int B, int C, int HW, void *workspace, size_t workspace_bytes, float *gram,
@@ -317,13 +415,26 @@ extern "C" int st3d_gram_fwd(const float *feat, int B, int C, int HW, void *work
     // whole tiles, whole 32-pixel chunks in every split, 16-byte aligned rows: the branch-free instantiation
     static const bool allow_fast = [] { const char *e = getenv("ST3D_GRAM_FAST"); return !(e && e[0] == '0'); }();
     const bool fast = allow_fast && C % TM == 0 && HW % 32 == 0 && g.kper % 32 == 0 && (((uintptr_t)feat) & 15) == 0;
+    static const bool tri = [] { const char *e = getenv("ST3D_GRAM_DIAG_TRI"); return !(e && e[0] == '0'); }();
+    if (fast && tri && (C == 64 || C == 128)) {     // upper blocks only, waves split the K chunk (gram_diag_kernel)
+        const int KG = gram_kgroups(C);
+        g.sC = g.sSplit * g.nsplit * KG;
+        if (C == 64) gram_diag_kernel<2><<<dim3(1, g.nsplit, B), 256, 0, s>>>(g);
+        else gram_diag_kernel<4><<<dim3(1, g.nsplit, B), 256, 0, s>>>(g);
+        ST3D_LAUNCH_CHECK();
+        gram_reduce_kernel<<<dim3(st3d::cdiv((long)C * C, 64), B), 256, 0, s>>>(g.C, g.nsplit * KG, C, 32, g.sSplit, g.sC, gram);
+        ST3D_LAUNCH_CHECK();
+        return ST3D_OK;
+    }
     if (g.tiles_n == 1) {           // one (diagonal) tile: A and B tiles coincide
         if (TM == 128) { if (fast) gemm_kernel<2, 2, 0, 1, 32, true><<<grid, 256, 0, s>>>(g); else gemm_kernel<2, 2, 0, 1><<<grid, 256, 0, s>>>(g); }
         else { if (fast) gemm_kernel<1, 1, 0, 1, 32, true><<<grid, 256, 0, s>>>(g); else gemm_kernel<1, 1, 0, 1><<<grid, 256, 0, s>>>(g); }
     } else if (TM == 128) { if (fast) gemm_kernel<2, 2, 0, 0, 32, true><<<grid, 256, 0, s>>>(g); else gemm_kernel<2, 2, 0><<<grid, 256, 0, s>>>(g); }
     else gemm_kernel<1, 1, 0><<<grid, 256, 0, s>>>(g);
     ST3D_LAUNCH_CHECK();
-    gram_reduce_kernel<<<dim3(st3d::cdiv((long)C * C, 64), B), 256, 0, s>>>(g.C, g.nsplit, C, TM, g.sSplit, g.sC, gram);
+    // mirror granularity: the multi-tile FAST launch leaves the lower-left 64 x 64 of its diagonal tiles unwritten
+    const int mirror = (fast && g.tiles_n > 1 && TM == 128) ? 64 : TM;
+    gram_reduce_kernel<<<dim3(st3d::cdiv((long)C * C, 64), B), 256, 0, s>>>(g.C, g.nsplit, C, mirror, g.sSplit, g.sC, gram);
     ST3D_LAUNCH_CHECK();
     return ST3D_OK;
 }
