@@ -29,6 +29,8 @@
 // of one XCD (dispatch is round-robin over the 8 XCDs) stream the same U slice from that XCD's L2.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -655,9 +657,10 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
 #ifndef ST3D_WINO_SCHED
 #define ST3D_WINO_SCHED 0
 #endif
-    int pb = 0;
-    for (int c = 0; c < nstages; ++c) {
-        const int pb1 = (pb == 2) ? 0 : pb + 1, pb2 = (pb1 == 2) ? 0 : pb1 + 1;
+    // The ring position is a compile-time constant of each copy of the stage (the loop is unrolled by the ring depth, 3):
+    // every LDS address is the lane's base plus an immediate, no per-stage address arithmetic on the vector ALU.
+    auto stage = [&](int c, auto PBc) __attribute__((always_inline)) {
+        constexpr int pb = decltype(PBc)::value, pb1 = (pb + 1) % 3, pb2 = (pb + 2) % 3;
         __builtin_amdgcn_sched_barrier(0);
         W4_MFMA(ua, bcur, 0)
         gload(min(c + 2, nstages - 1));
@@ -690,8 +693,15 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
-        pb = pb1;
+    };
+    int c = 0;
+    for (; c + 3 <= nstages; c += 3) {
+        stage(c, std::integral_constant<int, 0>{});
+        stage(c + 1, std::integral_constant<int, 1>{});
+        stage(c + 2, std::integral_constant<int, 2>{});
     }
+    if (c < nstages) stage(c, std::integral_constant<int, 0>{});
+    if (c + 1 < nstages) stage(c + 1, std::integral_constant<int, 1>{});
 #undef W4_ILV
 #undef W4_MFMA
 
