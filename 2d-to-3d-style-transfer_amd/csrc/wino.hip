@@ -37,6 +37,8 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int KC = 4;                 // input channels per MFMA sub-chunk (2 k-steps of 2)
@@ -443,7 +445,8 @@ constexpr int P4_STAGE = KS * PS4 + 8;            // 2312 floats per stage
 constexpr int EX4_FLOATS = 2 * 4 * 64 * 32;       // [2 j][4 a][64 co][32 tiles]
 constexpr int SMEM4_FLOATS = EX4_FLOATS > 3 * P4_STAGE ? EX4_FLOATS : 3 * P4_STAGE;      // 64 KB: two workgroups per CU use 128 of its 160 KB
 
-template <int MODE, int EPI, int DBG = 0>
+// GATE: 0 = plain outputs, 1 = outputs zeroed where a.gate <= 0, 2 = a.addc * (a.gate - a.addt) added first (EPI 0 only)
+template <int MODE, int EPI, int DBG = 0, int GATE = 0>
 __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[SMEM4_FLOATS];
     float *sP = smem;                          // [3][KS][PR4][PCP]
@@ -739,31 +742,48 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
     const int pair = tid & 15;                        // tiles 2 * pair, 2 * pair + 1 (same tile row)
     const int oy = y0 + 2 * (pair >> 3), ox = x0 + 4 * (pair & 7);
     const bool inb = oy < H && ox < W;                // H even, W % 4 == 0: the 2 x 4 pixel item is inside or outside
+    // Outputs (and the gate / content-target tiles) are addressed through buffer descriptors of image n with 32-bit byte
+    // offsets: the lane's offset once, the item's channel step as the scalar offset, out-of-image lanes at the sentinel --
+    // no 64-bit address arithmetic and no branch per item (the epilogue's vector-ALU work is paid in the neighbour
+    // workgroup's matrix-pipe time).
+    const unsigned out_bytes = (unsigned)((size_t)a.Cout * HW * 4);
+    const unsigned vo0 = inb ? (unsigned)((((size_t)co0 + (tid >> 4)) * HW + (size_t)oy * W + ox) * 4) : kOob;
+    const unsigned vo1 = inb ? vo0 + (unsigned)W * 4u : kOob;
+    const unsigned item_bytes = (unsigned)(16 * HW * 4);
     // the consumer's ReLU gate, applied here (a.gate: the tensor this gradient belongs to): fetched now -- the accumulators
     // are dead, and a load issued between the stores below would queue behind them -- and used after the exchange
-    f32x4 gq[4][2];
-    if (EPI == 0 && a.gate) {
+    f32x4 gq[GATE >= 1 ? 4 : 1][2], tq[GATE == 2 ? 4 : 1][2];
+    if (GATE >= 1) {
+        const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(a.gate + (size_t)n * a.Cout * HW), 0, out_bytes, 0x00020000);
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const float *gp = a.gate + ((size_t)n * a.Cout + co0 + it * 16 + (tid >> 4)) * HW + (size_t)oy * W + ox;
-            gq[it][0] = inb ? *reinterpret_cast<const f32x4 *>(gp) : f32x4{0.f, 0.f, 0.f, 0.f};
-            gq[it][1] = inb ? *reinterpret_cast<const f32x4 *>(gp + W) : f32x4{0.f, 0.f, 0.f, 0.f};
+            gq[it][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, vo0, it * item_bytes, 0));
+            gq[it][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, vo1, it * item_bytes, 0));
         }
     }
-    f32x4 tq[4][2];
-    if (EPI == 0 && a.gate && a.addt) {
+    if (GATE == 2) {
+        const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(a.addt + (size_t)n * a.Cout * HW), 0, out_bytes, 0x00020000);
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const float *tp = a.addt + ((size_t)n * a.Cout + co0 + it * 16 + (tid >> 4)) * HW + (size_t)oy * W + ox;
-            tq[it][0] = inb ? *reinterpret_cast<const f32x4 *>(tp) : f32x4{0.f, 0.f, 0.f, 0.f};
-            tq[it][1] = inb ? *reinterpret_cast<const f32x4 *>(tp + W) : f32x4{0.f, 0.f, 0.f, 0.f};
+            tq[it][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rt, vo0, it * item_bytes, 0));
+            tq[it][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rt, vo1, it * item_bytes, 0));
         }
+    }
+    __amdgpu_buffer_rsrc_t ry = rx, ryp = rx, ryi = rx;
+    if (a.y) ry = __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)n * a.Cout * HW, 0, out_bytes, 0x00020000);
+    const size_t HpWp = (size_t)Hp * Wp;
+    unsigned vp = kOob;
+    if (EPI == 1) {
+        ryp = __builtin_amdgcn_make_buffer_rsrc(a.yp + (size_t)n * a.Cout * HpWp, 0, (unsigned)(a.Cout * HpWp * 4), 0x00020000);
+        if (a.yidx) ryi = __builtin_amdgcn_make_buffer_rsrc(a.yidx + (size_t)n * a.Cout * HpWp, 0, (unsigned)(a.Cout * HpWp), 0x00020000);
+        if (inb) vp = (unsigned)((((size_t)co0 + (tid >> 4)) * HpWp + (size_t)(oy >> 1) * Wp + (ox >> 1)) * 4);
     }
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int col = it * 16 + (tid >> 4);         // cout within the workgroup's 64
-        const int co = co0 + col;
         f32x2 z[2][4];
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
@@ -779,47 +799,45 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
             for (int jj = 0; jj < 2; ++jj) {
                 float v0 = z[jj][0][t] + z[jj][1][t] + z[jj][2][t] + bsum;
                 float v1 = z[jj][1][t] - z[jj][2][t] - z[jj][3][t] + bsum;
-                if (a.relu) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
+                if (GATE == 0 && a.relu) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }     // (gated launches are input-gradients: no ReLU)
                 y[t][0][jj] = v0; y[t][1][jj] = v1;
             }
-        if (!inb) continue;
         if (DBG == 3 && y[0][0][0] != 12345.678f) continue;       // diagnostic: whole epilogue but no global stores
         if (a.y) {
-            float *dst = a.y + ((size_t)n * a.Cout + co) * HW + (size_t)oy * W + ox;
             f32x4 q0, q1;
             q0[0] = y[0][0][0]; q0[1] = y[0][0][1]; q0[2] = y[1][0][0]; q0[3] = y[1][0][1];
             q1[0] = y[0][1][0]; q1[1] = y[0][1][1]; q1[2] = y[1][1][0]; q1[3] = y[1][1][1];
-            if (EPI == 0 && a.gate) {
-                if (a.addt) {
+            if (GATE == 2) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        // unfused multiply / add: bitwise what st3d_axpy_diff (built without contraction) adds
-                        q0[e] = __fadd_rn(q0[e], __fmul_rn(a.addc, __fsub_rn(gq[it][0][e], tq[it][0][e])));
-                        q1[e] = __fadd_rn(q1[e], __fmul_rn(a.addc, __fsub_rn(gq[it][1][e], tq[it][1][e])));
-                    }
+                for (int e = 0; e < 4; ++e) {
+                    // unfused multiply / add: bitwise what st3d_axpy_diff (built without contraction) adds
+                    q0[e] = __fadd_rn(q0[e], __fmul_rn(a.addc, __fsub_rn(gq[it][0][e], tq[it][0][e])));
+                    q1[e] = __fadd_rn(q1[e], __fmul_rn(a.addc, __fsub_rn(gq[it][1][e], tq[it][1][e])));
                 }
+            }
+            if (GATE >= 1) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     q0[e] = gq[it][0][e] > 0.f ? q0[e] : 0.f;
                     q1[e] = gq[it][1][e] > 0.f ? q1[e] : 0.f;
                 }
             }
-            *reinterpret_cast<f32x4 *>(dst) = q0;
-            *reinterpret_cast<f32x4 *>(dst + W) = q1;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q0), ry, vo0, it * item_bytes, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q1), ry, vo1, it * item_bytes, 0);
         }
         if (EPI == 1) {     // MaxPool2d(2,2): first maximum in row-major window order (ATen); two adjacent windows per lane
-            f32x2 best; unsigned short bidx = 0;
+            f32x2 best; unsigned bidx = 0;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 float bv = y[t][0][0]; int bi = 0;
                 if (y[t][0][1] > bv || y[t][0][1] != y[t][0][1]) { bv = y[t][0][1]; bi = 1; }
                 if (y[t][1][0] > bv || y[t][1][0] != y[t][1][0]) { bv = y[t][1][0]; bi = 2; }
                 if (y[t][1][1] > bv || y[t][1][1] != y[t][1][1]) { bv = y[t][1][1]; bi = 3; }
-                best[t] = bv; bidx |= (unsigned short)(bi << (8 * t));
+                best[t] = bv; bidx |= (unsigned)(bi << (8 * t));
             }
-            const size_t po = ((size_t)n * a.Cout + co) * (size_t)Hp * Wp + (size_t)(oy >> 1) * Wp + (ox >> 1);
-            *reinterpret_cast<f32x2 *>(a.yp + po) = best;
-            if (a.yidx) *reinterpret_cast<unsigned short *>(a.yidx + po) = bidx;
+            const unsigned sp = (unsigned)(it * 16 * HpWp * 4);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, best), ryp, vp, sp, 0);
+            if (a.yidx) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)bidx, ryi, vp == kOob ? kOob : vp / 4, sp / 4, 0);
         }
     }
 }
@@ -901,7 +919,11 @@ int launch_wino4(WinoArgs a, hipStream_t s) {
     }
     if (dbgmode == 2 && MODE == 0) { if (a.yp) wino4_kernel<0, 1, 2><<<(unsigned)blocks, NT4, 0, s>>>(a); else wino4_kernel<0, 0, 2><<<(unsigned)blocks, NT4, 0, s>>>(a); return ST3D_OK; }
 #endif
-    if (a.yp) wino4_kernel<MODE, 1><<<(unsigned)blocks, NT4, 0, s>>>(a);
+    if (a.yp) wino4_kernel<MODE, 1><<<(unsigned)blocks, NT4, 0, s>>>(a);        // (forward: never gated)
+    else if (a.gate && a.addt) {
+        if (MODE != 0) { st3d::set_error("wino4: the content-target term rides on ungated input (MODE 0) only"); return ST3D_E_INVALID; }
+        wino4_kernel<0, 0, 0, 2><<<(unsigned)blocks, NT4, 0, s>>>(a);
+    } else if (a.gate) wino4_kernel<MODE, 0, 0, 1><<<(unsigned)blocks, NT4, 0, s>>>(a);
     else wino4_kernel<MODE, 0><<<(unsigned)blocks, NT4, 0, s>>>(a);
     ST3D_LAUNCH_CHECK();
     return ST3D_OK;
@@ -929,7 +951,8 @@ int launch_wino(WinoArgs a, hipStream_t s) {
 // (Cin*H*W < 2^29 floats); above that the callers fall back to the direct kernels of conv.hip (64-bit addressing).
 bool shape_ok(int Cin, int Cout, int H, int W) {
     return Cin >= 8 && (Cin % 8) == 0 && (Cout % 64) == 0 && (H % 2) == 0 && (W % 4) == 0 && H > 0 && W > 0 &&
-           (unsigned long long)Cin * (unsigned long long)H * (unsigned long long)W * 4ull < (1ull << 31);
+           (unsigned long long)Cin * (unsigned long long)H * (unsigned long long)W * 4ull < (1ull << 31) &&
+           (unsigned long long)Cout * (unsigned long long)H * (unsigned long long)W * 4ull < (1ull << 31);      // outputs: same addressing
 }
 
 }  // namespace
