@@ -232,6 +232,103 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         }
 }
 
+// Gram backward of the loss plan (st3d_gram_bwd_gated: D = G - S is SYMMETRIC, whole 128 x 64 tiles, aligned).  Same tile
+// shape and arithmetic as gemm_kernel<2, 1, 1> -- 128 channels x 64 pixels per workgroup, each wave 64 x 32, accumulators
+// started from the destination tile, coef folded into A, gate bits from the F chunk in LDS -- but written like the Winograd
+// loop: every global access goes through a buffer descriptor with a 32-bit lane offset and a scalar chunk / row offset (no
+// 64-bit address arithmetic, no bounds code), the A tile is read ALONG m from row k of D (= column k, by symmetry), so it
+// lands k-major in LDS with 16-byte stores instead of 16 transposing 4-byte ones, and the chunk loop is one basic block
+// with an explicit MFMA / LDS-read interleave and the next chunk's loads first.
+__global__ __launch_bounds__(256, 4) void gram_bwd_sym_kernel(const GemmArgs g) {
+    constexpr int TM = 128, TN = 64, KCH = 32, LA = TM + 4, LB = TN;
+    constexpr unsigned kOob = 0x80000000u;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) float As[KCH * LA];
+    __shared__ __attribute__((aligned(16))) float Bs[KCH * LB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ti = blockIdx.x / g.tiles_n, tj = blockIdx.x % g.tiles_n, b = blockIdx.z;
+    const int m0 = ti * TM, n0 = tj * TN;
+    const unsigned rowD = (unsigned)g.lda * 4u, rowF = (unsigned)g.ldb * 4u;      // bytes per row of D / of F and the result
+    const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.A + b * g.sA), 0,
+                                                                       (unsigned)g.K * rowD, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rF = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.B + b * g.sB), 0,
+                                                                       (unsigned)g.K * rowF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(g.C + b * g.sC, 0, (unsigned)g.M * rowF, 0x00020000);
+    // staging items: A 32 k-rows x 32 float4 (4 per thread), B 32 k-rows x 16 float4 (2 per thread)
+    unsigned voA[4], voB[2];
+    int loA[4], loB[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + i * 256, kr = e >> 5, mq = (e & 31) * 4;
+        voA[i] = (unsigned)kr * rowD + (unsigned)(m0 + mq) * 4u;
+        loA[i] = kr * LA + mq;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e = tid + i * 256, kr = e >> 4, nq = (e & 15) * 4;
+        voB[i] = (unsigned)kr * rowF + (unsigned)(n0 + nq) * 4u;
+        loB[i] = kr * LB + nq;
+    }
+    // this lane's rows of the result: m0 + 64 wm + 32 m + (r & 3) + 8 (r >> 2) + 4 lhi, column n0 + 32 wn + lane31
+    const unsigned voC = (unsigned)(m0 + wm * 64 + 4 * lhi) * rowF + (unsigned)(n0 + wn * 32 + l31) * 4u;
+    f32x16 acc[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            acc[m][r] = g.accumulate ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                           rC, voC, (unsigned)(m * 32 + (r & 3) + 8 * (r >> 2)) * rowF, 0))
+                                     : 0.f;
+    unsigned gmask[2] = {0xffffu, 0xffffu};
+    f32x4 av[4], bv[2];
+    auto gload = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) av[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rD, voA[i], (unsigned)k0 * rowD, 0));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) bv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rF, voB[i], (unsigned)k0 * rowF, 0));
+    };
+    gload(0);
+    const float *pa = As + lhi * LA + wm * 64 + l31;
+    const float *pb = Bs + lhi * LB + wn * 32 + l31;
+    for (int k0 = 0; k0 < g.K; k0 += KCH) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4 *>(&As[loA[i]]) = g.coef * av[i];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4 *>(&Bs[loB[i]]) = bv[i];
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        gload(min(k0 + KCH, g.K - KCH));            // (the last chunk re-requests itself: no branch in the loop)
+        if (g.gate) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+                if (m0 + wm * 64 + m * 32 == k0) {
+                    unsigned mk = 0;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        mk |= (Bs[((r & 3) + 8 * (r >> 2) + 4 * lhi) * LB + wn * 32 + l31] > 0.f ? 1u : 0u) << r;
+                    gmask[m] = mk;
+                }
+        }
+#pragma unroll
+        for (int kk = 0; kk < KCH / 2; ++kk) {
+            const float a0 = pa[(kk * 2) * LA], a1 = pa[(kk * 2) * LA + 32], bb = pb[(kk * 2) * LB];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bb, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bb, acc[1], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float o = ((gmask[m] >> r) & 1u) ? acc[m][r] : 0.f;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rC, voC,
+                                                  (unsigned)(m * 32 + (r & 3) + 8 * (r >> 2)) * rowF, 0);
+        }
+}
+
 // Gram forward of the single-tile layers (C = 64: NB = 2, C = 128: NB = 4 blocks of 32 channels), whole aligned shapes only.
 // The 4 waves of gemm_kernel<.., DIAG> tile the full C x C output, so a quarter (C = 64) to three eighths (C = 128) of
 // their MFMAs compute the mirror image of another wave's block.  Here only the NB (NB + 1) / 2 blocks on or above the
@@ -487,6 +584,15 @@ static int gram_bwd_launch(const float *D, const float *feat, int B, int C, int 
     }
     // (the branch-free FAST instantiation is forward-only: measured 3-8 % SLOWER on the backward shapes, with the explicit
     // schedule -- one or two LDS reads per MFMA -- and without it)
+    static const bool sym = [] { const char *e = getenv("ST3D_GRAM_BWD_SYM"); return !(e && e[0] == '0'); }();
+    if (gate && sym && !force && !k64 && C % 128 == 0 && HW % 64 == 0 && (size_t)C * HW * 4 < (1ull << 31) &&
+        (((uintptr_t)D | (uintptr_t)feat | (uintptr_t)gfeat) & 15) == 0) {
+        // the plan's call (symmetric D, whole tiles): the lean kernel
+        g.tiles_m = C / 128; g.tiles_n = HW / 64;
+        gram_bwd_sym_kernel<<<dim3(g.tiles_m * g.tiles_n, 1, B), 256, 0, s>>>(g);
+        ST3D_LAUNCH_CHECK();
+        return ST3D_OK;
+    }
     if (wide) {
         g.tiles_m = C / 128; g.tiles_n = st3d::cdiv(HW, 64);
         if (k64) gemm_kernel<2, 1, 1, 0, 64><<<dim3(g.tiles_m * g.tiles_n, 1, B), 256, 0, s>>>(g);
