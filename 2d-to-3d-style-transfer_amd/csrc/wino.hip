@@ -441,7 +441,14 @@ constexpr int T4_ROWS = 4, T4_COLS = 32;
 constexpr int NT4 = 256;
 constexpr int PR4 = T4_ROWS + 2;                  // 6 patch rows
 constexpr int PS4 = PR4 * PCP;                    // 288 floats per channel
-constexpr int P4_STAGE = KS * PS4 + 8;            // 2312 floats per stage
+#ifndef ST3D_WINO_KS
+#define ST3D_WINO_KS 8
+#endif
+constexpr int KS4 = ST3D_WINO_KS;                 // input channels staged per barrier: 8 (default) or 16 = 2 or 4 MFMA sub-chunks
+                                                  // (16 measured: one barrier per 64 MFMAs, but the prologue doubles -- conv1_2
+                                                  //  +11 %, conv4_x +1.5 %, 256 VGPRs with a spill: not taken)
+constexpr int NSUB4 = KS4 / KC;
+constexpr int P4_STAGE = KS4 * PS4 + 8;           // floats per stage
 constexpr int EX4_FLOATS = 2 * 4 * 64 * 32;       // [2 j][4 a][64 co][32 tiles]
 constexpr int SMEM4_FLOATS = EX4_FLOATS > 3 * P4_STAGE ? EX4_FLOATS : 3 * P4_STAGE;      // 64 KB: two workgroups per CU use 128 of its 160 KB
 
@@ -449,7 +456,7 @@ constexpr int SMEM4_FLOATS = EX4_FLOATS > 3 * P4_STAGE ? EX4_FLOATS : 3 * P4_STA
 template <int MODE, int EPI, int DBG = 0, int GATE = 0>
 __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[SMEM4_FLOATS];
-    float *sP = smem;                          // [3][KS][PR4][PCP]
+    float *sP = smem;                          // [3][KS4][PR4][PCP]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wa = tid >> 6;  // wave = row a of the Winograd domain
     const int l31 = lane & 31, lhi = lane >> 5;
@@ -478,10 +485,10 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
     const int Hp = H >> 1, Wp = W >> 1;
     constexpr bool UNPOOL = MODE == 2 || MODE == 3;     // MODE 3: the pooled gradient arrives already gated (pooled value > 0)
     const size_t in_plane = UNPOOL ? (size_t)Hp * Wp : HW;
-    const int nstages = a.Cin / KS;
+    const int nstages = a.Cin / KS4;
 
     // staging: 8 channels x 6 rows x 10 sixteen-byte items = 480 items per stage, two per thread
-    constexpr int ITEMS = KS * PR4 * 10, IPT = 2;
+    constexpr int ITEMS = KS4 * PR4 * 10, IPT = KS4 / 4;
     const unsigned kOob = 0x80000000u;
     unsigned voff[IPT];
     int loff[IPT];
@@ -501,10 +508,10 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
         }
         // the 32 threads without a second item write theirs (zeros: voff is out of range) into the stage's trailing slack:
         // no branch in lstore, so the stage loop is one basic block the scheduler can interleave
-        loff[i] = (e < ITEMS) ? (4 + ci * PS4 + r * PCP + 4 * l - 3) : (KS * PS4 + 4);
+        loff[i] = (e < ITEMS) ? (4 + ci * PS4 + r * PCP + 4 * l - 3) : (KS4 * PS4 + 4);
     }
     const unsigned img_bytes = (unsigned)((size_t)a.Cin * in_plane * 4);
-    const unsigned stage_bytes = (unsigned)(KS * in_plane * 4);
+    const unsigned stage_bytes = (unsigned)(KS4 * in_plane * 4);
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(a.x + (size_t)n * a.Cin * in_plane), 0, img_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t raux = rx, ridx = rx;
@@ -664,35 +671,38 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
     // every LDS address is the lane's base plus an immediate, no per-stage address arithmetic on the vector ALU.
     auto stage = [&](int c, auto PBc) __attribute__((always_inline)) {
         constexpr int pb = decltype(PBc)::value, pb1 = (pb + 1) % 3, pb2 = (pb + 2) % 3;
-        __builtin_amdgcn_sched_barrier(0);
-        W4_MFMA(ua, bcur, 0)
-        gload(min(c + 2, nstages - 1));
-        uload(2 * c + 1, ub);
-        pread(pb, 1, draw);
-        W4_ILV(0x120, ST3D_WINO_SCHED == 0 ? 1 : 2)               // vector-memory reads | LDS reads
-        __builtin_amdgcn_sched_barrier(0);
-        W4_MFMA(ua, bcur, 1)
-        bcompute(draw, bnext);
-        W4_ILV(0x002, 2)               // VALU
-        __builtin_amdgcn_sched_barrier(0);
-        W4_MFMA(ub, bnext, 0)
-        uload(2 * c + 2, ua);
-        pread(pb1, 0, draw);           // first sub-chunk of the NEXT stage (staged one barrier ago)
         Vals staged;
-        lgate(staged);                 // the gates of MODE 1-3 (VALU) ride in this quarter, the LDS writes in the next
-        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x120, ST3D_WINO_SCHED == 0 ? 1 : 2, 0);
-            if (MODE != 0) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        W4_MFMA(ub, bnext, 1)
-        bcompute(draw, bcur);
-        lwrite(pb2, staged);
-        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                       // LDS writes
+#pragma unroll
+        for (int sc = 0; sc < NSUB4; ++sc) {          // sub-chunk sc: its operands are ready in (ua | ub) / (bcur | bnext) by parity
+            Uop &ucur = (sc & 1) ? ub : ua;
+            Uop &unext = (sc & 1) ? ua : ub;
+            Bop &bc = (sc & 1) ? bnext : bcur;
+            Bop &bn = (sc & 1) ? bcur : bnext;
+            // memory quarter: the k-steps 0 of the sub-chunk || the patch items of stage c + 2 (first sub-chunk), the next
+            // sub-chunk's filter operands and patch reads (the last one reads the NEXT stage's buffer, staged a barrier ago),
+            // and in the last sub-chunk the gates of the items that arrived meanwhile
+            __builtin_amdgcn_sched_barrier(0);
+            W4_MFMA(ucur, bc, 0)
+            if (sc == 0) gload(min(c + 2, nstages - 1));
+            uload(NSUB4 * c + sc + 1, unext);
+            if (sc + 1 < NSUB4) pread(pb, sc + 1, draw);
+            else pread(pb1, 0, draw);
+            if (sc == NSUB4 - 1) lgate(staged);
+            _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x120, ST3D_WINO_SCHED == 0 ? 1 : 2, 0);
+                if (MODE != 0 && sc == NSUB4 - 1) __builtin_amdgcn_sched_group_barrier(0x002, KS4 / 2, 0);
+            }
+            // transform quarter: the k-steps 1 || the next sub-chunk's B operands (VALU), the ring writes in the last one
+            __builtin_amdgcn_sched_barrier(0);
+            W4_MFMA(ucur, bc, 1)
+            bcompute(draw, bn);
+            if (sc == NSUB4 - 1) lwrite(pb2, staged);
+            _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                if (sc == NSUB4 - 1) __builtin_amdgcn_sched_group_barrier(0x200, KS4 / 8, 0);       // LDS writes
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
@@ -950,7 +960,7 @@ int launch_wino(WinoArgs a, hipStream_t s) {
 // 0x80000000 as the out-of-image sentinel, so one image of the INPUT operand must stay below 2^31 bytes
 // (Cin*H*W < 2^29 floats); above that the callers fall back to the direct kernels of conv.hip (64-bit addressing).
 bool shape_ok(int Cin, int Cout, int H, int W) {
-    return Cin >= 8 && (Cin % 8) == 0 && (Cout % 64) == 0 && (H % 2) == 0 && (W % 4) == 0 && H > 0 && W > 0 &&
+    return Cin >= KS4 && (Cin % KS4) == 0 && (Cout % 64) == 0 && (H % 2) == 0 && (W % 4) == 0 && H > 0 && W > 0 &&
            (unsigned long long)Cin * (unsigned long long)H * (unsigned long long)W * 4ull < (1ull << 31) &&
            (unsigned long long)Cout * (unsigned long long)H * (unsigned long long)W * 4ull < (1ull << 31);      // outputs: same addressing
 }
