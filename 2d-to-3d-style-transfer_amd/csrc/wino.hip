@@ -446,7 +446,8 @@ constexpr int PS4 = PR4 * PCP;                    // 288 floats per channel
 #endif
 constexpr int KS4 = ST3D_WINO_KS;                 // input channels staged per barrier: 8 (default) or 16 = 2 or 4 MFMA sub-chunks
                                                   // (16 measured: one barrier per 64 MFMAs, but the prologue doubles -- conv1_2
-                                                  //  +11 %, conv4_x +1.5 %, 256 VGPRs with a spill: not taken)
+                                                  //  +11 %, conv4_x +1.5 %, 256 VGPRs with a spill: not taken; 4 -- one sub-chunk per
+                                                  //  barrier, operand parity alternating per stage -- was also measured: +4 % overall)
 constexpr int NSUB4 = KS4 / KC;
 constexpr int P4_STAGE = KS4 * PS4 + 8;           // floats per stage
 constexpr int EX4_FLOATS = 2 * 4 * 64 * 32;       // [2 j][4 a][64 co][32 tiles]
