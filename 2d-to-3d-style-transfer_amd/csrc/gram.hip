@@ -144,8 +144,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < A4; ++i) {
             const int e = tid + i * 256, row = e / (KCH / 4), kq = (e % (KCH / 4)) * 4;
-            As[(kq + 0) * LA + row] = g.coef * av[i].x; As[(kq + 1) * LA + row] = g.coef * av[i].y;
-            As[(kq + 2) * LA + row] = g.coef * av[i].z; As[(kq + 3) * LA + row] = g.coef * av[i].w;
+            const float cf = BMODE == 1 ? g.coef : 1.f;        // the forward has no coefficient: no multiply
+            As[(kq + 0) * LA + row] = cf * av[i].x; As[(kq + 1) * LA + row] = cf * av[i].y;
+            As[(kq + 2) * LA + row] = cf * av[i].z; As[(kq + 3) * LA + row] = cf * av[i].w;
         }
         if (diag) return;
 #pragma unroll
