@@ -8,13 +8,14 @@
 //   face_setup_kernel      (B*F threads)   gathers the 3 projected vertices of every face into a
 //                                          48-byte record (3 x float4) and packs the 16-pixel tiles its
 //                                          bounding box can touch into one 32-bit word
-//   raster_tile_kernel     one 256-thread workgroup per 16x16 pixel tile: the four waves sweep
-//                          the packed tile ranges 512 faces at a time (4 B per face, not the record),
-//                          compact the hits in face order (wave ballots), fetch only the hits'
-//                          records into LDS, then every lane (= pixel) walks the LDS list
+//   raster_tile_kernel     one 256-thread workgroup per 16x16 pixel tile: per super-round of 2048 faces every
+//                          wave sweeps the packed tile ranges of its own 512 faces (4 B per face, not the
+//                          record) and compacts the hits in face order (wave ballots) without a barrier; then
+//                          only the hits' records are fetched into LDS and every lane (= pixel) walks the list
 //                          (same-address broadcast reads, no bank conflicts).
-// Measured at config 2 (8 views, 512^2, cow): 0.20 ms, of which 0.055 ms is the sweep (mesh pushed off
-// screen); the rest is the per-pixel walk, bounded by the densest tiles (up to 330 one-pixel faces per
+// Measured at config 2 (8 views, 512^2, cow): 0.18 ms (0.19 before the sweep was decoupled from the record fetch,
+// round 2), of which ~0.05 ms is the sweep (mesh pushed off screen: every tile reads every face's word, 192 MB of L2
+// reads per 8-view batch); the rest is the per-pixel walk, bounded by the densest tiles (up to 330 one-pixel faces per
 // tile, 50 on average over the 32 % non-empty tiles).  Variants that did NOT help and were dropped
 // (tools/shade_bench.py): 1024 faces per pass (40 KB of LDS), prefetching records, bbox/area staged in
 // LDS with a sign early-out before the six divisions, one 8x8 quadrant per wave with wave-level culling.
@@ -29,7 +30,8 @@ namespace {
 
 constexpr float kEps = 1e-8f;
 constexpr int TILE = 16;       // 16x16 pixels per workgroup
-constexpr int LIST_CAP = 512;  // faces swept (and at most staged in LDS) per pass
+constexpr int LIST_CAP = 512;  // face records staged in LDS per walk
+constexpr int SUPER = 2048;    // faces swept per super-round (512 per wave)
 
 __device__ __forceinline__ float pix_to_ndc(int i, int S) { return -1.0f + (2.0f * (float)i + 1.0f) / (float)S; }
 
@@ -154,6 +156,7 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const float4 *__restri
     __shared__ float s_face[LIST_CAP][9];
     __shared__ int s_fidx[LIST_CAP];
     __shared__ int s_wcnt[4];
+    __shared__ int s_list[4][512];       // per wave: the faces of its slice of the super-round that touch this tile
 
     const int b = blockIdx.z;
     const int tid = threadIdx.x;
@@ -169,51 +172,62 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const float4 *__restri
     Best best;
     best.f = -1; best.z = 0.f; best.b0 = best.b1 = best.b2 = 0.f;
 
-    // sweep the packed tile ranges LIST_CAP = 512 faces per pass (2 consecutive faces per lane, one 8-byte load, the next
-    // pass's words prefetched), compact the hits in face order (ties in depth keep the smaller index), fetch only the
-    // hits' records into LDS, evaluate, repeat
-    uint2 wn = make_uint2(kEmptyRange, kEmptyRange);
-    if (2 * tid < Fp) wn = wb[tid];
-    for (int base = 0; base < Fp; base += LIST_CAP) {
-        const int f0 = base + 2 * tid;
-        const uint2 w2 = wn;
-        wn = make_uint2(kEmptyRange, kEmptyRange);
-        if (f0 + LIST_CAP < Fp) wn = wb[(f0 + LIST_CAP) >> 1];
-        const unsigned wv[2] = {w2.x, w2.y};
-        bool hit[2];
-        int before = 0, wave_total = 0;
+    // Two decoupled phases per super-round of 2048 faces (round 2; before, every 512-face pass had its own barrier ->
+    // record fetch -> barrier -> walk -> barrier chain, twelve times over for the cow):
+    //  1. sweep: every wave sweeps ITS 512 consecutive faces' packed tile ranges (4 x 8-byte loads per lane, all in flight
+    //     together) and compacts the hits, in face order, into its own index list -- no barrier, no record traffic;
+    //  2. one barrier; the four lists concatenated are the tile's faces in face order (ties in depth keep the smaller
+    //     index): their records are fetched into LDS in one go (chunks of LIST_CAP) and every lane (= pixel) walks them.
+    for (int base = 0; base < Fp; base += SUPER) {
+        int cnt = 0;
+        uint2 w4[4];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const unsigned w = wv[j];
-            hit[j] = (w & 255u) <= bx && bx <= ((w >> 8) & 255u) && ((w >> 16) & 255u) <= by && by <= (w >> 24);
-            const unsigned long long m = __ballot(hit[j]);
-            before += __popcll(m & ((1ull << lane) - 1ull));
-            wave_total += __popcll(m);
+        for (int it = 0; it < 4; ++it) {
+            const int f0 = base + 512 * wave + 128 * it + 2 * lane;
+            w4[it] = (f0 < Fp) ? wb[f0 >> 1] : make_uint2(kEmptyRange, kEmptyRange);
         }
-        if (lane == 0) s_wcnt[wave] = wave_total;
-        __syncthreads();
-        int off = 0;
-        for (int w = 0; w < wave; ++w) off += s_wcnt[w];
-        const int count = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
-        int mine = 0;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (hit[j]) {
-                const int f = f0 + j, slot = off + before + mine;
-                const float4 r0 = rb[3 * (size_t)f], r1 = rb[3 * (size_t)f + 1], r2 = rb[3 * (size_t)f + 2];
-                s_fidx[slot] = f;
-                s_face[slot][0] = r0.x; s_face[slot][1] = r0.y; s_face[slot][2] = r0.z;
-                s_face[slot][3] = r0.w; s_face[slot][4] = r1.x; s_face[slot][5] = r1.y;
-                s_face[slot][6] = r1.z; s_face[slot][7] = r1.w; s_face[slot][8] = r2.x;
-                ++mine;
+        for (int it = 0; it < 4; ++it) {
+            const int f0 = base + 512 * wave + 128 * it + 2 * lane;
+            const unsigned wv[2] = {w4[it].x, w4[it].y};
+            bool hit[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const unsigned w = wv[j];
+                hit[j] = (w & 255u) <= bx && bx <= ((w >> 8) & 255u) && ((w >> 16) & 255u) <= by && by <= (w >> 24);
             }
+            const unsigned long long m0 = __ballot(hit[0]), m1 = __ballot(hit[1]);
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            const int pos = cnt + __popcll(m0 & lt) + __popcll(m1 & lt);
+            if (hit[0]) s_list[wave][pos] = f0;
+            if (hit[1]) s_list[wave][pos + (hit[0] ? 1 : 0)] = f0 + 1;
+            cnt += __popcll(m0) + __popcll(m1);
         }
+        if (lane == 0) s_wcnt[wave] = cnt;
         __syncthreads();
-        for (int i = 0; i < count; ++i) {
-            eval_face(s_fidx[i], s_face[i][0], s_face[i][1], s_face[i][2], s_face[i][3], s_face[i][4], s_face[i][5],
-                      s_face[i][6], s_face[i][7], s_face[i][8], xf, yf, best);
+        const int o1 = s_wcnt[0], o2 = o1 + s_wcnt[1], o3 = o2 + s_wcnt[2], total = o3 + s_wcnt[3];
+        for (int cb = 0; cb < total; cb += LIST_CAP) {
+            const int n = min(LIST_CAP, total - cb);
+#pragma unroll
+            for (int h = 0; h < LIST_CAP / 256; ++h) {
+                const int slot = tid + 256 * h, i = cb + slot;
+                if (slot < n) {
+                    const int f = i < o1 ? s_list[0][i] : (i < o2 ? s_list[1][i - o1] : (i < o3 ? s_list[2][i - o2] : s_list[3][i - o3]));
+                    const float4 r0 = rb[3 * (size_t)f], r1 = rb[3 * (size_t)f + 1], r2 = rb[3 * (size_t)f + 2];
+                    s_fidx[slot] = f;
+                    s_face[slot][0] = r0.x; s_face[slot][1] = r0.y; s_face[slot][2] = r0.z;
+                    s_face[slot][3] = r0.w; s_face[slot][4] = r1.x; s_face[slot][5] = r1.y;
+                    s_face[slot][6] = r1.z; s_face[slot][7] = r1.w; s_face[slot][8] = r2.x;
+                }
+            }
+            __syncthreads();
+            for (int i = 0; i < n; ++i) {
+                eval_face(s_fidx[i], s_face[i][0], s_face[i][1], s_face[i][2], s_face[i][3], s_face[i][4], s_face[i][5],
+                          s_face[i][6], s_face[i][7], s_face[i][8], xf, yf, best);
+            }
+            __syncthreads();          // the record list (and, after the last chunk, the index lists) are rewritten next
         }
-        if (count) __syncthreads();          // (count is workgroup-uniform) the list is rewritten by the next pass
+        if (total == 0) __syncthreads();    // (workgroup-uniform) s_wcnt is rewritten by the next super-round
     }
     if (!in_img) return;
     const size_t p = ((size_t)b * S + py) * S + px;
