@@ -57,7 +57,7 @@ def build(force=False, jobs=4, verbose=True):
         if os.environ.get("ST3D_WINO_DEBUG") and src == "wino.hip":
             flags = flags + ["-DST3D_WINO_DEBUG"]      # s_memtime stamps for tools/wino_bench.py; never in the shipped library
         if src == "wino.hip":
-            for k in ("ST3D_WINO_SCHED", "ST3D_WINO_KS"):     # stage-loop schedule variants (A/B runs, tools/wino_sched_ab.sh)
+            for k in ("ST3D_WINO_SCHED", "ST3D_WINO_KS", "ST3D_WINO_UDEPTH"):     # stage-loop schedule variants (A/B runs, tools/wino_sched_ab.sh)
                 if os.environ.get(k):
                     flags = flags + ["-D%s=%s" % (k, os.environ[k])]
         if force or _newer(s, o, hdrs):

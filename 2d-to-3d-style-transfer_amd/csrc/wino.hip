@@ -637,8 +637,20 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
     lstore(0);
     gload(nstages > 1 ? 1 : 0);
     lstore(1);
+    // ST3D_WINO_UDEPTH (compile time): sub-chunks the filter operands are requested ahead of their MFMAs.  2 (three operand
+    // sets, 248-255 VGPRs, the default) against 1 (two sets): forward -1.2 %, conv1_2 forward -2.7 % -- 8 TB/s of L2 reads
+    // over all CUs are these operands, and one sub-chunk (16 MFMAs ~ 0.5 us) did not always cover their latency.
+#ifndef ST3D_WINO_UDEPTH
+#define ST3D_WINO_UDEPTH 2
+#endif
+#if ST3D_WINO_UDEPTH == 2
+    Uop u3[3];                 // filter operands two sub-chunks ahead (three sets)
+    uload(0, u3[0]);
+    uload(1, u3[1]);
+#else
     Uop ua, ub;
     uload(0, ua);
+#endif
     __syncthreads();
     Raw draw;
     Bop bcur, bnext;
@@ -675,8 +687,14 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
         Vals staged;
 #pragma unroll
         for (int sc = 0; sc < NSUB4; ++sc) {          // sub-chunk sc: its operands are ready in (ua | ub) / (bcur | bnext) by parity
+#if ST3D_WINO_UDEPTH == 2
+            constexpr int sub0 = (NSUB4 * pb) % 3;         // (the loop is unrolled by 3 stages: sub-chunk index mod 3 is static)
+            Uop &ucur = u3[(sub0 + sc) % 3];
+            Uop &unext = u3[(sub0 + sc + 2) % 3];
+#else
             Uop &ucur = (sc & 1) ? ub : ua;
             Uop &unext = (sc & 1) ? ua : ub;
+#endif
             Bop &bc = (sc & 1) ? bnext : bcur;
             Bop &bn = (sc & 1) ? bcur : bnext;
             // memory quarter: the k-steps 0 of the sub-chunk || the patch items of stage c + 2 (first sub-chunk), the next
@@ -685,7 +703,7 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             W4_MFMA(ucur, bc, 0)
             if (sc == 0) gload(min(c + 2, nstages - 1));
-            uload(NSUB4 * c + sc + 1, unext);
+            uload(NSUB4 * c + sc + ST3D_WINO_UDEPTH, unext);
             if (sc + 1 < NSUB4) pread(pb, sc + 1, draw);
             else pread(pb1, 0, draw);
             if (sc == NSUB4 - 1) lgate(staged);
