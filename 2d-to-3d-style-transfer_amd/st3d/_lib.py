@@ -23,6 +23,7 @@ SIGNATURES = {
     "st3d_device_info": (c_int, [c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_size), ctypes.c_char_p, c_int]),
     "st3d_project_verts": (c_int, [c_f32p, c_int, c_f32p, c_f32p, c_int, c_float, c_f32p, c_stream]),
     "st3d_raster_workspace_bytes": (c_size, [c_int, c_int]),
+    "st3d_raster_workspace_bytes_binned": (c_size, [c_int, c_int, c_int]),
     "st3d_raster_fwd": (c_int, [c_f32p, c_i32p, c_int, c_int, c_int, c_int, ctypes.c_void_p, c_size, c_i32p, c_f32p,
                                 c_f32p, c_f32p, c_float, c_i32p, c_stream]),
     "st3d_shade_fwd": (c_int, [c_i32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_int, c_int, c_int, c_int, c_int,

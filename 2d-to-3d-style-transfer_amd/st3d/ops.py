@@ -94,8 +94,8 @@ def raster_fwd(verts_ndc, faces_i32, S, z_clip=None):
     B, V, _ = verts_ndc.shape
     F = faces_i32.shape[0]
     dev = verts_ndc.device
-    ws_bytes = _lib.load().st3d_raster_workspace_bytes(B, F)
-    ws = torch.empty((ws_bytes // 4,), dtype=F32, device=dev)
+    ws_bytes = _lib.load().st3d_raster_workspace_bytes_binned(B, F, S)       # room for the coarse face bins too
+    ws = torch.empty(((ws_bytes + 3) // 4,), dtype=F32, device=dev)
     p2f = torch.empty((B, S, S), dtype=I32, device=dev)
     zbuf = torch.empty((B, S, S), dtype=F32, device=dev)
     bary = torch.empty((B, S, S, 3), dtype=F32, device=dev)

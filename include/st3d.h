@@ -52,6 +52,10 @@ int st3d_project_verts(const float *verts, int V, const float *R, const float *T
 
 /* bytes of scratch st3d_raster_fwd needs: per-view face records (48 B per face) + packed tile ranges (4 B per face) */
 size_t st3d_raster_workspace_bytes(int B, int F);
+/* the same + room for the coarse face bins of st3d_raster_fwd (lists of the faces touching each 64 x 64-pixel bin, built
+ * per call): with a workspace of this size a tile sweeps its bin's list instead of every face (meshes of more than 2048
+ * faces); with the smaller one st3d_raster_fwd keeps the flat sweep.  Same results either way. */
+size_t st3d_raster_workspace_bytes_binned(int B, int F, int S);
 
 /* Hard rasterisation (K=1, blur_radius=0, perspective-correct barycentrics).
  * faces (F,3) int32.  Outputs per view (B,S,S): pix_to_face int32 (-1 = background; the

@@ -108,6 +108,27 @@ CONV_CASES = [(2, 3, 64, 64, 64), (1, 64, 64, 48, 40), (2, 64, 128, 32, 32), (1,
               (1, 256, 256, 32, 32), (2, 512, 512, 16, 16), (1, 512, 512, 4, 4), (1, 3, 64, 33, 70)]
 
 
+@pytest.mark.parametrize("S,B", [(96, 2), (64, 1), (160, 3)])
+def test_raster_does_not_depend_on_stale_workspace_contents(dev, ops, cow, S, B):
+    """The rasteriser's workspace (face records, packed tile ranges, coarse bin lists) is a fresh torch.empty per call: it
+    must read nothing it has not written.  The caching allocator is primed with blocks full of 0xFF.. / small positive
+    integers (plausible face indices and counts) before each call; the fragments must equal the C oracle's bit for bit.
+    (Regression: the lanes past the last face carried the empty-range sentinel, which passes a RANGE overlap test with
+    the first bin -- phantom face indices in its list, harmless on zeroed memory, a fault on recycled memory.)"""
+    from oracle import render_ref as rr
+    R, T = _cams(B, seed=5)
+    faces = torch.from_numpy(cow["faces"].astype(np.int32)).to(dev)
+    ndc = ops.project_verts(torch.from_numpy(cow["verts"]).to(dev), torch.from_numpy(R).to(dev), torch.from_numpy(T).to(dev))
+    want = [rr.rasterize(rr.project_verts(cow["verts"], R[b], T[b]), cow["faces"], S, nthreads=8) for b in range(B)]
+    for poison in (-1, 7, 0x3fffffff):
+        junk = [torch.full((n,), poison, dtype=torch.int32, device=dev) for n in (1 << 22, 1 << 20, 1 << 18, 1 << 16)]
+        del junk
+        p2f, zbuf, bary, dists = ops.raster_fwd(ndc, faces, S)
+        for b in range(B):
+            np.testing.assert_array_equal(p2f[b].cpu().numpy(), want[b][0])
+            np.testing.assert_array_equal(zbuf[b].cpu().numpy(), want[b][1])
+
+
 @pytest.mark.parametrize("N,Cin,Cout,H,W", CONV_CASES)
 def test_conv3x3_fwd(dev, ops, N, Cin, Cout, H, W):
     torch.manual_seed(Cin * 7 + Cout)
