@@ -26,6 +26,15 @@ def pytest_sessionstart(session):
         g.build()
 
 
+    # ST3D_POISON_EMPTY=1: torch.empty() hands out memory filled with NaN / INT_MAX instead of whatever the allocator
+    # recycles -- every libst3d output and workspace is a torch.empty, so a kernel that reads before it writes shows up
+    # as a wrong result (or a loud fault) instead of depending on what ran before.  Off by default (costs a fill per empty).
+    if os.environ.get("ST3D_POISON_EMPTY", "0") not in ("", "0"):
+        import torch
+        torch.use_deterministic_algorithms(True, warn_only=True)
+        torch.utils.deterministic.fill_uninitialized_memory = True
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
