@@ -177,6 +177,10 @@ int dev_alloc(st3d_plan *p, T **ptr, size_t count) {
         return ST3D_E_NOMEM;
     }
     p->bytes += bytes;
+    // ST3D_POISON_PLAN=1 (tests): the plan's buffers start as 0xFF.. (NaN / -1) instead of whatever hipMalloc returns, so a
+    // launch that reads a buffer before the sequence has written it changes the result
+    static const bool poison = [] { const char *e = getenv("ST3D_POISON_PLAN"); return e && e[0] == '1'; }();
+    if (poison) (void)hipMemset(*ptr, 0xFF, bytes);
     return ST3D_OK;
 }
 
