@@ -52,6 +52,63 @@ __global__ __launch_bounds__(256) void finish_kernel(const float *__restrict__ p
     if (threadIdx.x == 0) out[0] = out[0] + (float)(s[0] * (double)scale);
 }
 
+// Several squared-difference sums in one launch pair (the loss tail of the plan: content + five style terms used to be
+// thirteen tiny launches).  Block -> item through the prefix table; every item keeps the decomposition, the partials and
+// the finishing tree it has alone (sqdiff_kernel + finish_kernel), and the items are folded into their slots in order,
+// so the sums are bitwise what the separate launches give.
+struct MultiArgs {
+    const float *a[8]; const float *b[8]; float *D[8];
+    size_t n[8], nb[8];
+    float scale[8];
+    int slot[8], first_block[9], count;
+};
+
+__global__ __launch_bounds__(256) void sqdiff_multi_kernel(const MultiArgs m, float *__restrict__ partials) {
+    int k = 0;
+    while (k + 1 < m.count && (int)blockIdx.x >= m.first_block[k + 1]) ++k;
+    const int lb = blockIdx.x - m.first_block[k], gsz = m.first_block[k + 1] - m.first_block[k];
+    const float *a = m.a[k], *b = m.b[k];
+    float *D = m.D[k];
+    const size_t n = m.n[k], nb = m.nb[k];
+    float acc = 0.f;
+    const size_t stride = (size_t)gsz * blockDim.x;
+    for (size_t i = (size_t)lb * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float d = a[i] - b[nb == n ? i : i % nb];
+        if (D) D[i] = d;
+        acc += d * d;
+    }
+    __shared__ float s[4];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[(size_t)k * NPART + lb] = (s[0] + s[1]) + (s[2] + s[3]);
+}
+
+__global__ __launch_bounds__(256) void finish_multi_kernel(const MultiArgs m, const float *__restrict__ partials, float *__restrict__ out,
+                                                           int zero_first, int combine, float sw, float cw) {
+    __shared__ double s[256];
+    __shared__ float acc3[3];
+    if (threadIdx.x < 3) acc3[threadIdx.x] = zero_first ? 0.f : out[threadIdx.x];
+    __syncthreads();
+    for (int k = 0; k < m.count; ++k) {
+        const int np = m.first_block[k + 1] - m.first_block[k];
+        double v = 0.0;
+        for (int i = threadIdx.x; i < np; i += 256) v += (double)partials[(size_t)k * NPART + i];
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) acc3[m.slot[k]] = acc3[m.slot[k]] + (float)(s[0] * (double)m.scale[k]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (combine) acc3[0] = cw * acc3[1] + sw * acc3[2];
+        out[0] = acc3[0]; out[1] = acc3[1]; out[2] = acc3[2];
+    }
+}
+
 // gate: also zero the result where a <= 0 (a is a post-ReLU activation: the ReLU gate of the gradient that lives in g)
 __global__ __launch_bounds__(256) void axpy_diff_kernel(const float *__restrict__ a, const float *__restrict__ b, size_t n,
                                                         float coef, int accumulate, int gate, float *__restrict__ g) {
@@ -189,6 +246,27 @@ extern "C" int st3d_sqdiff_sum(const float *a, const float *b, size_t n, size_t 
     sqdiff_kernel<<<gsz, 256, 0, s>>>(a, b, n, nb, D, partials);
     ST3D_LAUNCH_CHECK();
     finish_kernel<<<1, 256, 0, s>>>(partials, gsz, scale, loss_out);
+    ST3D_LAUNCH_CHECK();
+    return ST3D_OK;
+}
+
+extern "C" int st3d_sqdiff_sum_multi(const st3d_sqdiff_item *items, int count, float *partials, float *loss_out3, int zero_first,
+                                     int combine, float style_weight, float content_weight, st3d_stream_t stream) {
+    ST3D_CHECK_ARG(items && partials && loss_out3 && count > 0 && count <= 8);
+    MultiArgs m;
+    memset(&m, 0, sizeof(m));
+    m.count = count;
+    for (int k = 0; k < count; ++k) {
+        ST3D_CHECK_ARG(items[k].a && items[k].b && items[k].n > 0 && items[k].nb > 0 && items[k].n % items[k].nb == 0);
+        ST3D_CHECK_ARG(items[k].slot >= 0 && items[k].slot <= 2);
+        m.a[k] = items[k].a; m.b[k] = items[k].b; m.D[k] = items[k].D;
+        m.n[k] = items[k].n; m.nb[k] = items[k].nb; m.scale[k] = items[k].scale; m.slot[k] = items[k].slot;
+        m.first_block[k + 1] = m.first_block[k] + grid_for(items[k].n);
+    }
+    hipStream_t s = st3d::as_stream(stream);
+    sqdiff_multi_kernel<<<m.first_block[count], 256, 0, s>>>(m, partials);
+    ST3D_LAUNCH_CHECK();
+    finish_multi_kernel<<<1, 256, 0, s>>>(m, partials, loss_out3, zero_first, combine, style_weight, content_weight);
     ST3D_LAUNCH_CHECK();
     return ST3D_OK;
 }

@@ -206,8 +206,6 @@ struct Scope {   // HIP-event bracket around one kernel family (only when profil
 // F_CONV_*: the Winograd launches; F_CONVX_*: the convs Winograd does not cover (conv1_1, odd shapes, ST3D_CONV=direct)
 enum { F_CONV_FWD = 0, F_CONV_DGRAD = 1, F_POOL = 2, F_GRAM_FWD = 3, F_GRAM_BWD = 4, F_ELEM = 5, F_CONVX_FWD = 6, F_CONVX_DGRAD = 7 };
 
-__global__ void combine_loss_kernel(float *loss, float sw, float cw) { loss[0] = cw * loss[1] + sw * loss[2]; }
-
 // keep_full: also materialise the full-resolution output of convs whose 2x2 pool is fused into
 // their epilogue (needed only when a caller asks for that activation: st3d_plan_forward).
 int forward(st3d_plan *p, const float *imgs, int n, int upto, bool keep_full, hipStream_t s) {
@@ -363,7 +361,7 @@ extern "C" int st3d_plan_create(st3d_plan **out, st3d_vgg *vgg, int B, int S) {
     }
     p->gram_ws_bytes = wsmax;
     if (rc == ST3D_OK) { float *t = nullptr; rc = dev_alloc(p, &t, wsmax / sizeof(float)); p->gram_ws = t; }
-    if (rc == ST3D_OK) rc = dev_alloc(p, &p->partials, (size_t)st3d_reduce_partials());
+    if (rc == ST3D_OK) rc = dev_alloc(p, &p->partials, (size_t)8 * st3d_reduce_partials());
     if (rc == ST3D_OK) rc = dev_alloc(p, &p->g_in, (size_t)B * 3 * S * S);
     if (rc == ST3D_OK) rc = dev_alloc(p, &p->g_grad, (size_t)B * 3 * S * S);
     if (rc == ST3D_OK) rc = dev_alloc(p, &p->g_loss, (size_t)4);
@@ -525,18 +523,16 @@ extern "C" int st3d_plan_loss(st3d_plan *p, const float *current, int n, int bat
 static int plan_loss_enqueue(st3d_plan *p, const float *current, int n, int batch_denom, float style_weight,
                              float content_weight, float *loss_out, float *grad_current, hipStream_t s) {
     ST3D_TRY(forward(p, current, n, 28, false, s));
-    ST3D_HIP(hipMemsetAsync(loss_out, 0, 3 * sizeof(float), s));
 
     const double bd = (double)batch_denom;
     // content loss: mean over (B,C,H,W) of (F - Ft)^2            (losses.py:31)
+    // style loss: sum_l mean over (B,C,C) of (G - S)^2 / (C^2 H^2) (losses.py:34-39)
+    // -- the five Grams first, then all six squared-difference sums, their finish and the weighted total in one launch pair
     const int mc = kContentTap;
     const size_t chw = (size_t)p->C[mc] * p->H[mc] * p->W[mc];
-    {
-        Scope sc(p, F_ELEM, s);
-        ST3D_TRY(st3d_sqdiff_sum(p->act[mc], p->content_target, (size_t)n * chw, (size_t)n * chw,
-                                 (float)(1.0 / (bd * (double)chw)), nullptr, p->partials, loss_out + 1, s));
-    }
-    // style loss: sum_l mean over (B,C,C) of (G - S)^2 / (C^2 H^2) (losses.py:34-39)
+    st3d_sqdiff_item items[6];
+    items[0] = st3d_sqdiff_item{p->act[mc], p->content_target, nullptr, (size_t)n * chw, (size_t)n * chw,
+                                (float)(1.0 / (bd * (double)chw)), 1};
     float style_coef[5];
     for (int i = 0; i < 5; ++i) {
         const int m = kStyleTap[i];
@@ -547,15 +543,14 @@ static int plan_loss_enqueue(st3d_plan *p, const float *current, int n, int batc
         }
         const size_t cc = (size_t)p->C[m] * p->C[m];
         const double norm = 1.0 / (bd * C * C) / (C * C * Hh * Hh);
-        {
-            Scope sc(p, F_ELEM, s);
-            ST3D_TRY(st3d_sqdiff_sum(p->gram[i], p->style_gram[i], (size_t)n * cc, p->style_batch == 1 ? cc : (size_t)n * cc,
-                                     (float)norm, p->D[i], p->partials, loss_out + 2, s));
-        }
+        items[1 + i] = st3d_sqdiff_item{p->gram[i], p->style_gram[i], p->D[i], (size_t)n * cc,
+                                        p->style_batch == 1 ? cc : (size_t)n * cc, (float)norm, 2};
         style_coef[i] = (float)(4.0 * (double)style_weight * norm);   // d/dF = 2*(dG + dG^T)/2 ... = 4 w norm D F
     }
-    combine_loss_kernel<<<1, 1, 0, s>>>(loss_out, style_weight, content_weight);
-    ST3D_LAUNCH_CHECK();
+    {
+        Scope sc(p, F_ELEM, s);
+        ST3D_TRY(st3d_sqdiff_sum_multi(items, 6, p->partials, loss_out, 1, 1, style_weight, content_weight, s));
+    }
     if (!grad_current) return ST3D_OK;
 
     // ---- backward: gradient w.r.t. the post-ReLU output of each conv, top down

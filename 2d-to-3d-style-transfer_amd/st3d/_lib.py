@@ -79,6 +79,7 @@ SIGNATURES = {
     "st3d_gram_bwd_gated": (c_int, [c_f32p, c_f32p, c_int, c_int, c_int, c_float, c_int, c_f32p, c_stream]),
     "st3d_reduce_partials": (c_int, []),
     "st3d_sqdiff_sum": (c_int, [c_f32p, c_f32p, c_size, c_size, c_float, c_f32p, c_f32p, c_f32p, c_stream]),
+    "st3d_sqdiff_sum_multi": (c_int, [ctypes.c_void_p, c_int, c_f32p, c_f32p, c_int, c_int, c_float, c_float, c_stream]),
     "st3d_axpy_diff": (c_int, [c_f32p, c_f32p, c_size, c_float, c_int, c_f32p, c_stream]),
     "st3d_axpy_diff_gated": (c_int, [c_f32p, c_f32p, c_size, c_float, c_int, c_f32p, c_stream]),
     "st3d_masked_mse": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_f32p, c_f32p, c_f32p, c_stream]),

@@ -245,6 +245,20 @@ int st3d_gram_bwd_gated(const float *D, const float *feat, int B, int C, int HW,
 int st3d_reduce_partials(void);
 int st3d_sqdiff_sum(const float *a, const float *b, size_t n, size_t nb, float scale, float *D,
                     float *partials, float *loss_out, st3d_stream_t stream);
+/* Up to 8 squared-difference sums in one launch pair (the plan's loss tail): item k adds scale * sum((a - b)^2) over n
+ * elements (b with period nb; D = a - b when non-NULL) into loss_out3[slot], slot in {0, 1, 2}; zero_first clears the
+ * three slots first; combine != 0 then sets loss_out3[0] = content_weight * loss_out3[1] + style_weight * loss_out3[2]
+ * (losses.py:41-44).  Every item keeps the decomposition and the summation tree of st3d_sqdiff_sum: same bits.
+ * partials: count * st3d_reduce_partials() floats. */
+typedef struct st3d_sqdiff_item {
+    const float *a; const float *b; float *D;
+    size_t n, nb;
+    float scale;
+    int slot;
+} st3d_sqdiff_item;
+int st3d_sqdiff_sum_multi(const st3d_sqdiff_item *items, int count, float *partials, float *loss_out3,
+                          int zero_first, int combine, float style_weight, float content_weight,
+                          st3d_stream_t stream);
 /* content loss backward: g (+)= coef * (a - b)  */
 int st3d_axpy_diff(const float *a, const float *b, size_t n, float coef, int accumulate, float *g,
                    st3d_stream_t stream);
