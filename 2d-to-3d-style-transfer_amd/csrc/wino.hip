@@ -499,7 +499,7 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
         const int e = tid + i * NT4;
         const int ci = e / (PR4 * 10), rem = e - ci * (PR4 * 10);
         const int r = rem / 10, l = rem - r * 10;
-        const int gy = y0 + r - 1, gx0 = x0 - 4 + 4 * l;
+        const int gy = (DBG == 9 ? 8 : y0) + r - 1, gx0 = (DBG == 9 ? 32 : x0) - 4 + 4 * l;
         const bool ok = e < ITEMS && gy >= 0 && gy < H && gx0 >= 0 && gx0 < W;
         if (UNPOOL) {
             voff[i] = ok ? (unsigned)((ci * in_plane + (size_t)(gy >> 1) * Wp + (gx0 >> 1)) * 4) : kOob;
@@ -652,6 +652,18 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
     uload(0, ua);
 #endif
     __syncthreads();
+    if (DBG == 8 || DBG == 9) {       // diagnostics: from here on (8: the loop) the patch loads hit one cache-resident tile / (9) are real again
+        const int fx = DBG == 8 ? 32 : x0, fy = DBG == 8 ? 8 : y0;
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) {
+            const int e = tid + i * NT4;
+            const int ci = e / (PR4 * 10), rem = e - ci * (PR4 * 10);
+            const int r = rem / 10, l = rem - r * 10;
+            const int gy = fy + r - 1, gx0 = fx - 4 + 4 * l;
+            const bool ok = e < ITEMS && gy >= 0 && gy < H && gx0 >= 0 && gx0 < W;
+            voff[i] = ok ? (unsigned)((ci * in_plane + (size_t)gy * W + gx0) * 4) : kOob;
+        }
+    }
     Raw draw;
     Bop bcur, bnext;
     pread(0, 0, draw);
@@ -944,6 +956,11 @@ int launch_wino4(WinoArgs a, hipStream_t s) {
     if ((dbgmode == 3 || dbgmode == 4) && MODE == 0) {
         if (dbgmode == 3) { if (a.yp) wino4_kernel<0, 1, 3><<<(unsigned)blocks, NT4, 0, s>>>(a); else wino4_kernel<0, 0, 3><<<(unsigned)blocks, NT4, 0, s>>>(a); }
         else { if (a.yp) wino4_kernel<0, 1, 4><<<(unsigned)blocks, NT4, 0, s>>>(a); else wino4_kernel<0, 0, 4><<<(unsigned)blocks, NT4, 0, s>>>(a); }
+        return ST3D_OK;
+    }
+    if ((dbgmode == 8 || dbgmode == 9) && MODE == 0) {
+        if (dbgmode == 8) { if (a.yp) wino4_kernel<0, 1, 8><<<(unsigned)blocks, NT4, 0, s>>>(a); else wino4_kernel<0, 0, 8><<<(unsigned)blocks, NT4, 0, s>>>(a); }
+        else { if (a.yp) wino4_kernel<0, 1, 9><<<(unsigned)blocks, NT4, 0, s>>>(a); else wino4_kernel<0, 0, 9><<<(unsigned)blocks, NT4, 0, s>>>(a); }
         return ST3D_OK;
     }
     if (dbgmode == 2 && MODE == 0) { if (a.yp) wino4_kernel<0, 1, 2><<<(unsigned)blocks, NT4, 0, s>>>(a); else wino4_kernel<0, 0, 2><<<(unsigned)blocks, NT4, 0, s>>>(a); return ST3D_OK; }
