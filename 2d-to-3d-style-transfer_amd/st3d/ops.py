@@ -47,11 +47,14 @@ def project_verts(verts, R, T):
 # raise a device flag when a rasterised face has a vertex nearer than z_clip.  The flag travels to pinned host memory
 # without blocking and is looked at when a later call finds its copy complete (or by check_near_plane(block=True)).
 # Policy (ST3D_NEAR_PLANE, default "clip"): from then on every render of the process goes through the general kernels,
-# which clip exactly like PyTorch3D (st3d.render.render_views asks near_plane_triggered()), with one warning -- a vertex
-# optimisation that drives the mesh into the near plane (bob, 'both', lr 0.01: after ~80 steps) keeps running like the
-# reference does; the one or two frames rendered before the flag arrived were rendered unclipped.  "raise": fail loudly.
+# which clip exactly like PyTorch3D (st3d.render.render_views asks near_plane_triggered()), with one warning.  "raise":
+# fail loudly.  This asynchronous watch is the safety net of DIRECT raster_fwd callers: st3d.render.render_views asks
+# reaches_near_plane() BEFORE it renders (round 3), so through the renderer no frame is ever rendered unclipped -- a vertex
+# optimisation that drives the mesh into the near plane (bob, 'both', lr 0.01: after ~80 steps) moves to the clipping
+# kernels with the first such frame and keeps running like the reference does.
 _NEAR_PENDING = []
 _NEAR_TRIGGERED = False
+_NEAR_WARNED = False
 NEAR_PLANE_POLICY = os.environ.get("ST3D_NEAR_PLANE", "clip")
 NEAR_PLANE_MESSAGE = ("a rasterised face has a vertex nearer than z_clip_value (PyTorch3D clips meshes at znear / 2 = 0.5); the "
                       "specialised K = 1 kernels do not clip -- construct RasterizationSettings(z_clip_value=0.5) to render "
@@ -63,9 +66,19 @@ def near_plane_triggered():
 
 
 def reset_near_plane():
-    global _NEAR_TRIGGERED
-    _NEAR_TRIGGERED = False
+    global _NEAR_TRIGGERED, _NEAR_WARNED
+    _NEAR_TRIGGERED = _NEAR_WARNED = False
     _NEAR_PENDING.clear()
+
+
+def note_near_plane():
+    """One warning per process the first time a render is sent to the clipping kernels."""
+    global _NEAR_WARNED
+    if not _NEAR_WARNED:
+        import warnings
+        warnings.warn("st3d: the mesh reached the near clipping plane (z < znear / 2); rendering continues on the general "
+                      "kernels, which clip like PyTorch3D (ST3D_NEAR_PLANE=raise turns this into an error)")
+        _NEAR_WARNED = True
 
 
 def check_near_plane(block=False):
@@ -81,10 +94,7 @@ def check_near_plane(block=False):
             _NEAR_PENDING.clear()
             if NEAR_PLANE_POLICY == "raise":
                 raise RuntimeError(NEAR_PLANE_MESSAGE)
-            if not _NEAR_TRIGGERED:
-                import warnings
-                warnings.warn("st3d: the mesh reached the near clipping plane (z < znear / 2); rendering continues on the general "
-                              "kernels, which clip like PyTorch3D (ST3D_NEAR_PLANE=raise turns this into an error)")
+            note_near_plane()
             _NEAR_TRIGGERED = True
 
 

@@ -8,8 +8,9 @@ Multi-GPU: one process per GPU, each rank renders/VGGs its slice 
 batch with the loss means divided by the GLOBAL batch; ``step()`` all-reduces (SUM) the flat
 gradient of every parameter over RCCL (torch.distributed backend "nccl" == RCCL on ROCm,
 xGMI inside a node) and then every rank applies the identical Adam update -- parameters stay
-replicated without a broadcast.  The message is 3 MiB at 512^2 (one launch-latency-bound
-collective per step); view-independent terms (mesh regularisers) must be added after the
+replicated without a broadcast.  The gradients of ALL parameters travel as one flat buffer
+[d verts || d texture], so a step has exactly ONE collective: 3 MiB (+ 12*V bytes)
+at 512^2, launch-latency bound; view-independent terms (mesh regularisers) must be added after the
 reduce or scaled by 1/world.
 """
 import os
@@ -48,10 +49,31 @@ def shard_views(n_views, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def _world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
 def all_reduce_sum_(t):
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _world() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
+
+
+def comm_info(device=None):
+    """What the process group really is, for bench / log lines: backend name, the number of ranks that answered a SUM
+    all-reduce of ones ON THAT BACKEND (not WORLD_SIZE read back from the environment), the collective library version."""
+    info = {"dist_backend": None, "ranks_seen": 1, "rccl_version": None}
+    if _world() > 1:
+        info["dist_backend"] = dist.get_backend()
+        one = torch.ones(1, device=device if info["dist_backend"] == "nccl" or device is not None else "cpu")
+        dist.all_reduce(one)
+        info["ranks_seen"] = int(one.item())
+        if info["dist_backend"] == "nccl":
+            try:
+                info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception as e:              # the version is a report, not a dependency
+                info["rccl_version"] = "unavailable: %r" % (e,)
+    return info
 
 
 class Adam:
@@ -71,6 +93,8 @@ class Adam:
         self.lr = self.param_groups[0]["lr"]
         self.state = {}
         self.reduce_grads = reduce_grads
+        self._flat = None                   # [grad of param 0 || grad of param 1 || ...]: the one message of a step
+        self.collectives = 0                # all-reduces issued so far (tests: one per step whatever the parameter count)
 
     def zero_grad(self, set_to_none=True):
         for p in self.params:
@@ -88,15 +112,46 @@ class Adam:
             self.state[id(p)] = st
         return st
 
+    def _reduced_grads(self):
+        """{id(p): gradient summed over ranks}.  One parameter: its gradient is reduced in place.  Several: they are
+        packed into one persistent flat buffer in construction order (for setup_optimizations('both'): vertices, then
+        texture), reduced by ONE collective, and handed on as views of that buffer."""
+        live = [p for p in self.params if p.grad is not None]
+        grads = {id(p): p.grad.contiguous() for p in live}
+        if not (self.reduce_grads and _world() > 1) or not live:
+            return grads
+        if len(live) < len(self.params):
+            # a collective must have the same length on every rank; a rank that skipped a parameter would desynchronise it
+            raise RuntimeError("st3d Adam: with several ranks every parameter needs a gradient on every rank "
+                               "(ranks without views contribute zeros: cli.Run.zero_contribution)")
+        if len(live) == 1:
+            all_reduce_sum_(grads[id(live[0])])
+        else:
+            n = sum(g.numel() for g in grads.values())
+            if self._flat is None or self._flat.numel() != n or self._flat.device != live[0].device:
+                self._flat = torch.empty(n, dtype=torch.float32, device=live[0].device)
+            views, off = {}, 0
+            for p in live:
+                g = grads[id(p)]
+                v = self._flat[off:off + g.numel()]
+                v.copy_(g.reshape(-1))
+                views[id(p)] = v.view(g.shape)
+                off += g.numel()
+            all_reduce_sum_(self._flat)
+            grads = views
+            for p in live:                  # like the in-place single-parameter case: p.grad holds the summed gradient
+                p.grad = views[id(p)]
+        self.collectives += 1
+        return grads
+
     @torch.no_grad()
     def step(self):
+        grads = self._reduced_grads()
         for group in self.param_groups:
             for p in group["params"]:
-                if p.grad is None:
+                g = grads.get(id(p))
+                if g is None:
                     continue
-                g = p.grad.contiguous()
-                if self.reduce_grads:
-                    all_reduce_sum_(g)
                 st = self._state_of(p)
                 st["step"] += 1
                 if not p.is_contiguous():

@@ -382,26 +382,66 @@ def uses_hard_path(raster_settings, blend_params):
     return bp is None or (bp.sigma, bp.gamma, bp.background_color) == (1e-4, 1e-4, (1.0, 1.0, 1.0))
 
 
+_DEPTH_CACHE = {}
+
+
+def reaches_near_plane(verts, R, T, z_clip):
+    """True if any vertex lies nearer than `z_clip` to any of the cameras (view depth = X_world R[:, :, 2] + T[2]).
+    PyTorch3D clips every mesh at z_clip before rasterising; the specialised K = 1 kernels do not, so render_views asks
+    BEFORE it renders and sends such a batch to the clipping kernels -- no frame is ever rendered unclipped.  The answer
+    needs one host read of a device scalar: for tensors that are not being optimised it is cached on their identity and
+    version (texture-only runs: one read per camera batch, ever); vertices under optimisation are asked every step (the
+    read waits for the previous step, ~1 % of a config-5 step)."""
+    v = verts.detach()
+    key = None
+    if not verts.requires_grad:
+        key = (v.data_ptr(), v._version, tuple(v.shape), R.data_ptr(), R._version, T.data_ptr(), T._version, R.shape[0],
+               float(z_clip), str(v.device))
+        hit = _DEPTH_CACHE.get(key)
+        if hit is not None:
+            return hit[0]
+    zmin = (v.to(torch.float32) @ R[:, :, 2].to(torch.float32).t() + T[:, 2].to(torch.float32)).min()
+    near = bool(zmin.item() < z_clip)
+    if key is not None:
+        if len(_DEPTH_CACHE) > 256:
+            _DEPTH_CACHE.clear()
+        _DEPTH_CACHE[key] = (near, verts, R, T)         # keep the keyed tensors alive: their addresses stay unique
+    return near
+
+
 def render_views(meshes, R, T, image_size, raster_settings=None, blend_params=None):
-    """All B views in one batch of launches -> (rgb (B,3,S,S), coverage (B,1,S,S)).  Coverage is the 0/1 mask on
-    the hard path and softmax_rgb_blend's alpha on the soft path; both satisfy ``coverage > 0`` == covered."""
+    """All B views in one batch of launches -> (rgb (B,3,S,S), coverage (B,1,S,S)).  Coverage is the 0/1 mask under
+    the reference's hard settings (whichever kernels render them) and softmax_rgb_blend's alpha under soft settings;
+    both satisfy ``coverage > 0`` == covered."""
     tex = meshes.textures
     dev = meshes.device
     rs, bp = raster_settings, blend_params
-    if uses_hard_path(rs, bp) and ops.near_plane_triggered():
-        # the specialised kernels do not clip and this process has seen a mesh at the near plane: same settings on the
-        # general kernels with PyTorch3D's default clipping depth (ops.check_near_plane)
+    R, T = R.to(dev), T.to(dev)
+    hard_settings = uses_hard_path(rs, bp)
+    if hard_settings and (ops.near_plane_triggered() or
+                          reaches_near_plane(meshes.verts_packed(), R, T, RasterizationSettings.Z_CLIP_DEFAULT)):
+        # the specialised kernels do not clip: a mesh at the near plane renders with the same settings on the general
+        # kernels at PyTorch3D's default clipping depth.  Every rank decides for its own views; both kernel families give
+        # the same pixels where nothing is clipped, so ranks need not agree.
+        if ops.NEAR_PLANE_POLICY == "raise":
+            raise RuntimeError(ops.NEAR_PLANE_MESSAGE)
+        ops.note_near_plane()
         rs = RasterizationSettings(image_size=image_size, z_clip_value=RasterizationSettings.Z_CLIP_DEFAULT)
     if uses_hard_path(rs, bp):
         # K=1, blur 0: the blend weight cancels and the pixel is the sampled texel itself (SURVEY.md A.4)
         return _RenderFn.apply(meshes.verts_packed(), tex.maps_padded(), meshes.faces_i32(), tex.verts_uvs_padded(),
-                               tex.faces_uvs_i32(), R.to(dev), T.to(dev), int(image_size))
+                               tex.faces_uvs_i32(), R, T, int(image_size))
     bp = bp if bp is not None else BlendParams()
     rs = rs if rs is not None else RasterizationSettings(image_size=image_size)
-    return _SoftRenderFn.apply(meshes.verts_packed(), tex.maps_padded(), meshes.faces_i32(), tex.verts_uvs_padded(),
-                               tex.faces_uvs_i32(), R.to(dev), T.to(dev), int(image_size), rs.faces_per_pixel,
-                               rs.blur_radius, rs.clip_barycentric_coords, bp.sigma, bp.gamma, bp.background_color,
-                               rs.cull_backfaces, rs.perspective_correct, rs.z_clip)
+    rgb, alpha = _SoftRenderFn.apply(meshes.verts_packed(), tex.maps_padded(), meshes.faces_i32(), tex.verts_uvs_padded(),
+                                     tex.faces_uvs_i32(), R, T, int(image_size), rs.faces_per_pixel,
+                                     rs.blur_radius, rs.clip_barycentric_coords, bp.sigma, bp.gamma, bp.background_color,
+                                     rs.cull_backfaces, rs.perspective_correct, rs.z_clip)
+    if hard_settings:
+        # the caller asked for the hard configuration and is handed what the hard path hands out: the 0/1 coverage mask
+        # (alpha of a K = 1 / blur 0 blend is in [0.5, 1) on covered pixels; the reference thresholds it, utils.py:72)
+        alpha = (alpha.detach() > 0).to(torch.float32)
+    return rgb, alpha
 
 
 class MeshRenderer:

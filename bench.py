@@ -67,10 +67,24 @@ def gram_alg_flops(module, S, B):
 
 
 def gram_fwd_issued_fraction(module):
-    """The forward computes only 128x128 tiles on/above the diagonal (gram.hip)."""
+    """MFMA work the Gram forward ISSUES over the full C x C product (gram.hip): only blocks on or above the diagonal
+    exist -- 32x32 blocks in gram_diag_kernel (C = 64: 3 of 4, C = 128: 10 of 16), 64x64 wave tiles in the multi-tile
+    launches (the mirror wave of a diagonal 128x128 tile sits the MFMAs out: C = 256 10 of 16, C = 512 36 of 64)."""
     C = STYLE_TAPS[module][0]
-    t = max(C // 128, 1)
-    return (t * (t + 1) / 2) / (t * t)
+    n = C // 32 if C <= 128 else C // 64
+    return (n * (n + 1) / 2) / (n * n)
+
+
+def check_fractions(obj, path="line"):
+    """Every roofline fraction in the line is a fraction: fail loudly instead of printing a number above 1."""
+    if isinstance(obj, dict):
+        for k, v in obj.items():
+            if k in ("frac", "mfma_frac", "hbm_frac") and v is not None:
+                assert 0.0 <= v <= 1.0, "%s.%s = %r is not a fraction of a roofline" % (path, k, v)
+            check_fractions(v, path + "." + str(k))
+    elif isinstance(obj, list):
+        for i, v in enumerate(obj):
+            check_fractions(v, "%s[%d]" % (path, i))
 
 
 def load_assets(size, device, mesh="cow", style_k=1):
@@ -161,15 +175,22 @@ def main():
                     help="optimization_target (BASELINE configs[1] = texture; configs[4] = both)")
     args = ap.parse_args()
 
-    if not os.path.exists(os.path.join(PKG, "lib", "libst3d.so")) and int(os.environ.get("RANK", "0")) == 0 \
-            and int(os.environ.get("WORLD_SIZE", "1")) == 1:
-        import __graft_entry__ as _ge           # a checkout without the prebuilt library: compile it (there is no CPU fallback)
-        _ge.build()
-    from st3d import optim as st3d_optim
-    rank, world, local = st3d_optim.init_distributed()
-    if world != args.gpus:
+    from st3d import launch as st3d_launch
+    if not st3d_launch.under_launcher():
+        # the parent process: nothing here has touched a GPU yet (importing torch does not)
+        if not os.path.exists(os.path.join(PKG, "lib", "libst3d.so")):
+            import __graft_entry__ as _ge       # a checkout without the prebuilt library: compile it (there is no CPU fallback)
+            _ge.build()
         if args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
+            # `python bench.py --gpus N` on its own: one fresh child per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as
+            # torch.distributed.run would set them), rank 0's JSON line relayed, non-zero exit if any rank fails
+            sys.exit(st3d_launch.self_launch(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
+    from st3d import optim as st3d_optim
+    if st3d_optim.dist_info()[1] != args.gpus:      # (checked before the rendezvous, which would wait for the missing ranks)
+        world = st3d_optim.dist_info()[1]
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher environment says WORLD_SIZE={world}; start it as "
+                         f"`python bench.py --gpus {args.gpus}` or under torch.distributed.run with --nproc-per-node {args.gpus}")
+    rank, world, local = st3d_optim.init_distributed()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libst3d has no CPU fallback")
     device = torch.device(f"cuda:{local % max(torch.cuda.device_count(), 1)}")     # > device_count only in gloo rehearsals
@@ -224,10 +245,18 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    comm = {}
     if world > 1:       # RCCL builds its communicator lazily on the first collective: keep that out of the timed steps even at --warmup 0
         torch.distributed.all_reduce(torch.zeros(texture_map.numel(), device=device))
+        comm = st3d_optim.comm_info(device)         # backend, ranks that answered a SUM of ones, RCCL version
+        ids = [None] * world
+        torch.distributed.all_gather_object(ids, "%s #%d" % (torch.cuda.get_device_name(device), device.index))
+        comm["devices_seen"] = ids
+    first_loss = None
     for _ in range(args.warmup):
-        step()
+        loss = step()
+        if first_loss is None:
+            first_loss = loss.detach().clone()
     barrier()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
@@ -235,23 +264,28 @@ def main():
     for i in range(args.steps):
         loss = step()
         marks[i + 1].record()
+        if first_loss is None:
+            first_loss = loss.detach().clone()
     barrier()
     elapsed = time.perf_counter() - t0
     dev_ms = marks[0].elapsed_time(marks[-1])
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     median_ms = per_step[len(per_step) // 2]
-    final_loss = float(loss.detach())
-    allreduce_ms = None
+    final_loss, first_step_loss = float(loss.detach()), float(first_loss)
+    collectives_per_step = optimizer.collectives / float(max(args.warmup + args.steps, 1))
+    allreduce_ms = allreduce_ms_min = None
     if world > 1:
-        # the one collective of the step, timed on its own right after the timed region (same tensor size, same stream)
-        g = torch.zeros_like(texture_map)
+        # the one collective of the step (the flat gradient buffer of all optimised tensors), timed on its own right after
+        # the timed region (same message size, same stream)
+        g = torch.zeros(sum(q.numel() for q in optimizer.params), device=device)
         allreduce_ms = time_ms(lambda: torch.distributed.all_reduce(g), reps=20, warm=3)
-        t = torch.tensor([elapsed, dev_ms, median_ms, allreduce_ms], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed, dev_ms, median_ms, allreduce_ms, -allreduce_ms], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed, dev_ms, median_ms, allreduce_ms = (float(x) for x in t)
-        lt = torch.tensor([final_loss], device=device, dtype=torch.float64)
+        elapsed, dev_ms, median_ms, allreduce_ms, allreduce_ms_min = (float(x) for x in t)
+        allreduce_ms_min = -allreduce_ms_min
+        lt = torch.tensor([final_loss, first_step_loss], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(lt)
-        final_loss = float(lt[0])
+        final_loss, first_step_loss = float(lt[0]), float(lt[1])
 
     kernels, layers = None, None
     nprof = 5
@@ -431,22 +465,30 @@ def main():
                        "global_views_per_step": global_views, "texture": "%dx%d" % (S, S),
                        "targets_hoisted": not args.no_hoist,
                        "parallelism": "views sharded dp%d, RCCL all-reduce of the texture gradient" % world},
-            "final_loss": final_loss,
+            "first_step_loss": first_step_loss, "final_loss": final_loss,
             "roofline": roofline,
             "step_roofline": step_roofline,
         }
         if allreduce_ms is not None:
-            res["allreduce_ms"] = round(allreduce_ms, 4)
-            res["allreduce_bytes"] = int(texture_map.numel() * 4)
+            res.update(comm)
+            res["collectives_per_step"] = collectives_per_step
+            res["allreduce_ms"] = round(allreduce_ms, 4)                # slowest rank
+            res["allreduce_ms_min"] = round(allreduce_ms_min, 4)        # fastest rank
+            res["allreduce_bytes"] = int(sum(q.numel() for q in optimizer.params) * 4)
         if kernels:
             res["kernels"] = kernels
         if layers and args.layers:
             res["layers"] = layers
         if not args.no_cpu_baseline and world == 1:
             try:
-                res["cpu_baseline"] = cpu_baseline(S, Bv, 0)
+                res["cpu_baseline"] = cb = cpu_baseline(S, Bv, 0)
+                if std_cfg:
+                    # same seed-0 cameras, same initial texture: the CPU restatement's (first and only) step and the GPU's
+                    # first step compute the same loss
+                    cb["loss_rel_diff_vs_gpu_first_step"] = abs(cb["loss"] - first_step_loss) / abs(cb["loss"])
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 res["cpu_baseline"] = {"value": None, "error": repr(e)}
+        check_fractions(res)
         print(json.dumps(res))
     if world > 1:
         torch.distributed.barrier()

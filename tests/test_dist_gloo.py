@@ -77,3 +77,58 @@ def test_dist_info_defaults(monkeypatch):
     assert O.dist_info() == (0, 1, 0)
     t = torch.ones(3)
     assert O.all_reduce_sum_(t) is t and torch.equal(t, torch.ones(3))     # no process group: identity
+
+
+_RANK_SCRIPT = """
+import json, os, sys
+sys.path.insert(0, %r)
+import torch
+from st3d import optim as O
+rank, world, _ = O.init_distributed(backend="gloo")
+if len(sys.argv) > 1 and sys.argv[1] == "fail" and rank == 1:
+    sys.exit(7)
+# two parameters (vertices, then texture -- utils.setup_optimizations('both') order): ONE collective per step
+verts, tex = torch.nn.Parameter(torch.zeros(5, 3)), torch.nn.Parameter(torch.zeros(1, 4, 4, 3))
+opt = O.Adam([verts, tex], lr=0.01)
+sums = []
+for it in range(3):
+    verts.grad = torch.full((5, 3), float(rank + 1 + it))
+    tex.grad = torch.arange(48, dtype=torch.float32).reshape(1, 4, 4, 3) * (rank + 1)
+    g = opt._reduced_grads()
+    sums.append([float(g[id(verts)][0, 0]), float(g[id(tex)].reshape(-1)[47]), float(verts.grad[0, 0])])
+info = O.comm_info()
+print("noise that is not the result line")
+if rank == 0:
+    print(json.dumps({"world": world, "collectives": opt.collectives, "sums": sums, "flat": opt._flat.numel(), **info}))
+torch.distributed.barrier()
+torch.distributed.destroy_process_group()
+"""
+
+
+def test_self_launcher_starts_ranks_relays_rank0_and_packs_all_gradients_into_one_collective(tmp_path):
+    """st3d.launch (what `python bench.py --gpus N` uses when no torchrun wrapped it): N fresh children with the torchrun
+    environment on a free port, rank 0's stdout captured, a failing rank stops the job with its exit code.  Inside the
+    ranks: Adam packs [d verts || d texture] into one flat buffer -- one all-reduce per step whatever the parameter count
+     -- and comm_info() counts the ranks on the backend itself."""
+    import json
+    from st3d import launch
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT % os.path.join(ROOT, "2d-to-3d-style-transfer_amd"))
+    rc, out = launch.spawn_ranks(2, [sys.executable, str(script)], timeout=300)
+    assert rc == 0, out
+    res = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+    assert res["world"] == 2 and res["ranks_seen"] == 2 and res["dist_backend"] == "gloo"
+    assert res["collectives"] == 3 and res["flat"] == 15 + 48
+    # rank r contributes (r + 1 + it) and 47 (r + 1): sums over ranks 0, 1; p.grad holds the reduced gradient afterwards
+    assert res["sums"] == [[3.0 + 2 * it, 47.0 * 3, 3.0 + 2 * it] for it in range(3)]
+    rc, _ = launch.spawn_ranks(3, [sys.executable, str(script), "fail"], timeout=300)
+    assert rc == 7
+
+
+def test_rank_env_is_what_torchrun_would_set():
+    from st3d import launch
+    env = launch.rank_env(2, 4, 12345, base={})
+    assert env["RANK"] == "2" and env["LOCAL_RANK"] == "2" and env["WORLD_SIZE"] == "4"
+    assert env["MASTER_ADDR"] == "127.0.0.1" and env["MASTER_PORT"] == "12345"
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert launch.free_port() > 0

@@ -105,3 +105,36 @@ def test_c_abi_collective_world_of_one():
     assert torch.equal(x, y)
     assert lib.st3d_allreduce_sum_f32(h, None, 4, None) == -1
     call("st3d_comm_destroy", h)
+
+
+@pytest.mark.parametrize("target,n_params", [("texture", 1), ("both", 2)])
+def test_bench_gpus_2_launches_its_own_ranks_and_reports_what_ran(target, n_params):
+    """`python bench.py --gpus 2` with NO torchrun around it (what the driver runs on a multi-GPU node): the parent starts
+    two fresh ranks before any GPU call, rank 0's line is the only thing on stdout, and the line proves what ran --
+    `ranks_seen` is a SUM all-reduce of ones on the process group's backend, one collective per step even with two
+    optimised tensors (flat [d verts || d texture] buffer).  gloo here because both ranks share the one GPU of the box;
+    on the 8-GPU node the same code path runs on RCCL."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env["ST3D_DIST_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+           "--size", "256", "--views", "2", "--target", target]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(out) == 1, r.stdout
+    line = json.loads(out[0])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["dist_backend"] == "gloo"
+    assert len(line["devices_seen"]) == 2
+    assert line["collectives_per_step"] == 1.0
+    assert line["allreduce_bytes"] == 4 * (256 * 256 * 3 + (2930 * 3 if n_params == 2 else 0))
+    assert line["allreduce_ms"] >= line["allreduce_ms_min"] > 0
+    assert line["config"]["global_views_per_step"] == 4 and line["value"] > 0
+    assert np.isfinite(line["final_loss"]) and np.isfinite(line["first_step_loss"])
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29612")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr

@@ -652,9 +652,9 @@ def test_soft_raster_backward_through_clipped_faces_matches_fp64_autograd(dev, o
 def test_renderer_near_plane_policy(dev, cow, monkeypatch):
     """PyTorch3D clips at z_clip_value = znear / 2.  Through MeshRenderer: an explicit z_clip_value renders on the general
     kernels WITH clipping (pixels against the oracle's clipped fragments, gradients flow); the specialised K = 1 path does
-    not clip and must say so -- a render whose mesh reaches the plane is noticed at the next check: by default the process
-    switches to the clipping kernels (one warning), under ST3D_NEAR_PLANE=raise it fails; the reference's own views
-    (nothing nearer than 0.78) never trip the watch."""
+    not clip, so the renderer asks for the vertices' nearest depth BEFORE it renders: a batch that reaches the plane goes to the
+    clipping kernels (one warning; 0/1 mask as the hard settings promise), under ST3D_NEAR_PLANE=raise it fails; the
+    reference's own views (nothing nearer than 0.78) stay on the specialised kernels."""
     import utils as U
     from oracle import render_ref as rr
     from st3d import ops as O
@@ -688,24 +688,39 @@ def test_renderer_near_plane_policy(dev, cow, monkeypatch):
         b, _ = clipping.render(mesh, far)
     np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=2e-6)
     O.check_near_plane(block=True)
-    # near view on the specialised path, policy "raise": loud
+    # near view under the reference's hard settings, policy "raise": loud, BEFORE anything is rendered
     monkeypatch.setattr(O, "NEAR_PLANE_POLICY", "raise")
-    with torch.no_grad():
+    with torch.no_grad(), pytest.raises(RuntimeError, match="z_clip_value"):
         plain.render(mesh, near)
-    with pytest.raises(RuntimeError, match="z_clip_value"):
-        O.check_near_plane(block=True)
-    O.check_near_plane(block=True)                      # the failure is reported once
-    # default policy "clip": one warning, and from then on the SAME renderer object renders through the clipping kernels
+    # default policy "clip": the FIRST such frame already goes through the clipping kernels (one warning per process) and the
+    # renderer still hands out what its hard settings promise: the 0/1 coverage mask (alpha in [0.5, 1) leaked)
     monkeypatch.setattr(O, "NEAR_PLANE_POLICY", "clip")
     try:
         with torch.no_grad():
-            plain.render(mesh, near)                    # unclipped frame; raises the flag
             with pytest.warns(UserWarning, match="near clipping plane"):
-                O.check_near_plane(block=True)
-            assert O.near_plane_triggered()
-            c, ccov = plain.render(mesh, near)
-        np.testing.assert_array_equal((ccov[0, 0] > 0).cpu().numpy(), frag[0][..., 0] >= 0)
+                c, ccov = plain.render(mesh, near)
+            assert not O.near_plane_triggered()         # decided per render from the vertices' depths, nothing sticky
+            c2, m2 = U.render_meshes(plain, mesh, near)
+            a2, _ = plain.render(mesh, far)             # and the next far view is back on the specialised kernels
+        covered = frag[0][..., 0] >= 0
+        for cov_t in (ccov, m2):
+            assert set(np.unique(cov_t.cpu().numpy()).tolist()) <= {0.0, 1.0}
+            np.testing.assert_array_equal(cov_t[0, 0].cpu().numpy() == 1.0, covered)
         np.testing.assert_allclose(c[0].cpu().numpy(), ref_rgb, atol=3e-6)
+        np.testing.assert_allclose(c2[0].cpu().numpy(), ref_rgb, atol=3e-6)
+        np.testing.assert_array_equal(a2.cpu().numpy(), a.cpu().numpy())
+        # vertices under optimisation are asked every step (no cache): moving the SAME tensor into the plane is noticed
+        from st3d.render import reaches_near_plane
+        R, T = far.R, far.T
+        vv = torch.from_numpy(cow["verts"]).to(dev)
+        assert not reaches_near_plane(vv, R, T, 0.5) and not reaches_near_plane(vv, R, T, 0.5)
+        vv += (torch.tensor([0.0, 0.0, -1.7], device=dev) @ R[0].t())          # in place: same address, new version
+        assert reaches_near_plane(vv, R, T, 0.5)
+        # the asynchronous watch of DIRECT st3d_raster_fwd callers (no renderer in between) still raises its flag
+        ndc = O.project_verts(torch.from_numpy(cow["verts"]).to(dev), near.R, near.T)
+        O.raster_fwd(ndc, mesh.faces_i32(), S, z_clip=0.5)
+        O.check_near_plane(block=True)
+        assert O.near_plane_triggered()
     finally:
         O.reset_near_plane()
     assert not O.near_plane_triggered()
