@@ -4,6 +4,9 @@
 // associative, so any order -- lanes, tiles, views -- gives the same bits.  The scale is a power of two chosen from a
 // bound on the magnitude of any partial sum (the sum of the absolute contributions, reduced in a fixed order by a first
 // pass), so nothing can overflow and the quantisation step is 2^-60 of that bound -- far below fp32 resolution of the sums.
+// A NaN or an infinity in the scattered values makes the bound non-finite: the header is then poisoned (inv = NaN) and the
+// conversion pass writes NaN into every element -- a diverged run fails as loudly as it does with float atomics or in the
+// reference, instead of the integer conversion laundering the NaN into a finite number.
 //
 // workspace layout: [DetHeader][partials float x det_partials][int64 accumulators x n]
 #pragma once
@@ -46,6 +49,10 @@ static __global__ __launch_bounds__(256) void det_scale_kernel(const float *__re
         if (k < -1000) k = -1000;
         hdr->scale = ldexp(1.0, k);
         hdr->inv = ldexp(1.0, -k);
+        if (!(bound >= 0.0 && bound < 1e300)) {     // NaN / Inf upstream: poison the result (bound is a sum of |.|, never < 0)
+            hdr->scale = 0.0;
+            hdr->inv = __longlong_as_double(0x7ff8000000000000ll);
+        }
     }
 }
 

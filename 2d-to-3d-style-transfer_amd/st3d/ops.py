@@ -198,19 +198,20 @@ def project_verts_bwd(verts, R, T, grad_ndc, out=None):
 
 
 def mesh_reg(verts, target, topo, weights, want_grad=True):
-    """topo: dict(edges (E,2) i32, nbr_off (V+1) i32, nbr_idx i32, pairs (P,4) i32).
+    """topo: dict(edges (E,2) i32, nbr_off (V+1) i32, nbr_idx i32, pairs (P,4) i32, pair_off (V+1) i32, pair_ref (4P) i32).
     -> (loss_out [weighted total, mse, edge, laplacian, normal], grad_verts (V,3) or None)"""
     verts, target = _f32c(verts), _f32c(target)
     V = verts.shape[0]
     dev = verts.device
-    scratch = torch.empty((3 * V,), dtype=F32, device=dev)
+    P = topo["pairs"].shape[0]
+    scratch = torch.empty((_lib.load().st3d_mesh_reg_scratch_floats(V, P),), dtype=F32, device=dev)
     parts = torch.empty((4 * _lib.load().st3d_reduce_partials(),), dtype=F32, device=dev)
     out = torch.zeros((5,), dtype=F32, device=dev)
     g = torch.zeros_like(verts) if want_grad else None
     w = (ctypes.c_float * 4)(*[float(x) for x in weights])
-    P = topo["pairs"].shape[0]
     call("st3d_mesh_reg", dptr(verts), dptr(target), V, dptr(topo["edges"], I32), topo["edges"].shape[0],
-         dptr(topo["nbr_off"], I32), dptr(topo["nbr_idx"], I32), dptr(topo["pairs"], I32) if P else None, P, w,
+         dptr(topo["nbr_off"], I32), dptr(topo["nbr_idx"], I32), dptr(topo["pairs"], I32) if P else None, P,
+         dptr(topo["pair_off"], I32) if P else None, dptr(topo["pair_ref"], I32) if P else None, w,
          dptr(scratch), dptr(parts), dptr(out), dptr(g), stream_ptr())
     return out, g
 

@@ -284,12 +284,18 @@ int st3d_range_loss(const float *values, size_t n, float *partials, float *loss_
  * mesh_edge_loss (target length 0), mesh_laplacian_smoothing('uniform'), mesh_normal_consistency
  * for one mesh, forward + gradient in one call.  Topology is static and precomputed by the host:
  * edges (E,2) unique undirected; CSR vertex adjacency nbr_off (V+1), nbr_idx; pairs (P,4) =
- * (v0, v1, a, b) for every two faces sharing edge (v0,v1) with opposite vertices a, b.
- * weights: host float[4] = {verts_mse, edge, laplacian, normal}.  scratch >= 3*V floats,
- * partials >= 4*st3d_reduce_partials() floats.  loss_out: device float[5] = {weighted sum, mse,
- * edge, laplacian, normal} (unweighted terms).  grad_verts (V,3) += weighted gradient. */
+ * (v0, v1, a, b) for every two faces sharing edge (v0,v1) with opposite vertices a, b; and the
+ * inverse of `pairs`: pair_off (V+1), pair_ref = for each vertex the entries (pair * 4 + column)
+ * of `pairs` that name it, ascending.  Every gradient is a per-vertex gather over these static
+ * lists in a fixed order -- no float atomics, bitwise reproducible (round 3).
+ * weights: host float[4] = {verts_mse, edge, laplacian, normal}.  scratch >=
+ * st3d_mesh_reg_scratch_floats(V, P) floats, partials >= 4*st3d_reduce_partials() floats.
+ * loss_out: device float[5] = {weighted sum, mse, edge, laplacian, normal} (unweighted terms).
+ * grad_verts (V,3) += weighted gradient. */
+size_t st3d_mesh_reg_scratch_floats(int V, int P);
 int st3d_mesh_reg(const float *verts, const float *target_verts, int V, const int32_t *edges, int E,
                   const int32_t *nbr_off, const int32_t *nbr_idx, const int32_t *pairs, int P,
+                  const int32_t *pair_off, const int32_t *pair_ref,
                   const float *weights, float *scratch, float *partials, float *loss_out,
                   float *grad_verts, st3d_stream_t stream);
 

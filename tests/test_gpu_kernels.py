@@ -383,6 +383,48 @@ def test_mesh_regularisers_match_oracle(dev, ops, cow):
     assert abs(out[0].item() - total.item()) <= 1e-5 * abs(total.item())
     rel = (grad.cpu().double() - vd.grad).norm() / vd.grad.norm()
     assert float(rel) <= 1e-4, float(rel)
+    # round 3: every gradient is a fixed-order gather over static CSR lists (no float atomics): bitwise reproducible
+    for _ in range(3):
+        out2, grad2 = ops.mesh_reg(verts.to(dev), target.to(dev), topo, w)
+        assert torch.equal(grad2, grad) and torch.equal(out2, out)
+    # the per-vertex inverse of `pairs`: vertex k is named exactly by the entries listed for it, ascending
+    po, pr, flat = topo["pair_off"].cpu().numpy(), topo["pair_ref"].cpu().numpy(), topo["pairs"].cpu().numpy().reshape(-1)
+    assert po[0] == 0 and po[-1] == flat.size == pr.size
+    for k in (0, 1, 17, verts.shape[0] - 1):
+        mine = pr[po[k]:po[k + 1]]
+        assert (flat[mine] == k).all() and (np.diff(mine) > 0).all() and mine.size == (flat == k).sum()
+
+
+def test_fixed_point_scatters_propagate_non_finite_gradients(dev, ops, cow):
+    """A NaN / Inf in the upstream gradient must come out of the render backward as NaN in BOTH scatter modes (ADVICE r2:
+    the fixed-point path used to launder it into a finite number via the integer conversion, so a diverged run kept
+    stepping silently; the float-atomic path and the reference propagate it)."""
+    S, T = 64, 32
+    R, Tt = _cams(1, seed=3)
+    verts = torch.from_numpy(cow["verts"]).to(dev)
+    faces = torch.from_numpy(cow["faces"]).to(dev).to(torch.int32)
+    uvs = torch.from_numpy(cow["verts_uvs"]).to(dev)
+    fuv = torch.from_numpy(cow["faces_uvs"]).to(dev).to(torch.int32)
+    tex = torch.rand((T, T, 3), generator=torch.Generator().manual_seed(0)).to(dev)
+    ndc = ops.project_verts(verts, torch.from_numpy(R).to(dev), torch.from_numpy(Tt).to(dev))
+    frag = ops.raster_fwd(ndc, faces, S)
+    covered = (frag[0][0] >= 0).nonzero()
+    y, x = [int(v) for v in covered[covered.shape[0] // 2]]
+    try:
+        for det in (True, False):
+            ops.set_deterministic(det)
+            for bad in (float("nan"), float("inf")):
+                g = torch.randn((1, 3, S, S), generator=torch.Generator().manual_seed(1)).to(dev)
+                clean_t, clean_b = ops.shade_bwd(g, frag, uvs, fuv, tex, want_bary=True)
+                assert torch.isfinite(clean_t).all()
+                assert torch.isfinite(ops.raster_bwd(clean_b, frag[0], ndc, faces)).all()
+                g[0, 1, y, x] = bad
+                gt, gb = ops.shade_bwd(g, frag, uvs, fuv, tex, want_bary=True)
+                assert not torch.isfinite(gt).all(), (det, bad)
+                gv = ops.raster_bwd(gb, frag[0], ndc, faces)
+                assert not torch.isfinite(gv).all(), (det, bad)
+    finally:
+        ops.set_deterministic(True)
 
 
 # ---------------------------------------------------------------------------- Winograd F(2x2,3x3) conv
