@@ -10,6 +10,7 @@
 //   backward = "NN": A = D (M=C, K=C), B = F as [K][N=HW].
 // Arithmetic intensity is 32 flop/B per 128x128 tile (A/B tiles re-read through L2), at the
 // fp32 ridge for C = 64 where F (the largest activation) is streamed exactly once.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -520,22 +521,36 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const float *__restric
     gram_reduce_body(slab, nsplit, C, TM, sSplit, sB, gram, blockIdx.x, blockIdx.y, part);
 }
 
+// the slab reductions of all layers in one launch (same fixed tree per element as gram_reduce_kernel)
+__global__ __launch_bounds__(256) void gram_reduce_multi_kernel(const ReduceMulti m) {
+    __shared__ float part[4][64];
+    int b = blockIdx.x, it = 0;
+    while (it + 1 < m.n_items && b >= m.first[it + 1]) ++it;
+    b -= m.first[it];
+    const ReduceItem &r = m.r[it];
+    gram_reduce_body(r.slab, r.nsplit, r.C, r.TM, r.sSplit, r.sB, r.gram, b % r.blocks_per_image, b / r.blocks_per_image, part);
+}
+
 // K split: enough workgroups to fill the chip a few times over (256 CUs x 2 resident workgroups x 1..4), but
 // at least 8 K-chunks of work per workgroup and at most 256 slabs.
-int gram_split(int B, int C, int HW, int *kper) {
+// scale > 1 (the multi-layer launch): a layer no longer has to fill the chip on its own -- the other layers' blocks run
+// beside it -- so it takes 1/scale of the workgroups, each over scale x the pixels: 1/scale of the slab traffic
+// (a slab is C x C floats per split: at scale 1 the five layers write and re-read 0.4 GB of slabs per step, against 1.0 GB
+// of activations read).
+int gram_split(int B, int C, int HW, int *kper, int scale = 1) {
     const int nt = (C % 128 == 0) ? C / 128 : (C + 63) / 64;
     const int pairs = nt * (nt + 1) / 2;
     // workgroups aimed for, measured per style layer of config 2 (tools/gram_sweep.py): the deep layers (few tiles,
     // short K) want more, thinner splits; C = 128 fewer
     // (round 2 re-measured with the split count itself, ST3D_GRAM_NSPLIT: 256 channels at 128^2 32 splits 145 vs 162 us at
     // 64; 512 at 64^2 16 splits 144 vs 149 at 26; 512 at 32^2 8 splits 69 vs 76 at 4)
-    const int target = C >= 512 ? 1280 : (C == 256 ? 768 : (C == 128 ? 512 : 1024));
+    const int target = (C >= 512 ? 1280 : (C == 256 ? 768 : (C == 128 ? 512 : 1024))) / scale;
     int ns = (target + pairs * B - 1) / (pairs * B);
     if (const char *ev = getenv("ST3D_GRAM_TARGET_WGS")) {       // tuning knob (tools/gram_sweep.py): workgroups aimed for
         const int t = atoi(ev);
         if (t > 0) ns = (t + pairs * B - 1) / (pairs * B);
     }
-    const int ns_bytes = (HW + 2047) / 2048;            // never more than 2048 pixels per workgroup
+    const int ns_bytes = (HW + 2048 * scale - 1) / (2048 * scale);      // never more than 2048 (x scale) pixels per workgroup
     if (ns < ns_bytes) ns = ns_bytes;
     const int ns_max = (HW + 4 * KCH0 - 1) / (4 * KCH0);   // at least 4 K-chunks (128 pixels) of work per workgroup
     if (ns > ns_max) ns = ns_max;
@@ -563,34 +578,56 @@ extern "C" size_t st3d_gram_workspace_bytes(int B, int C, int HW) {
     return (size_t)B * ns * gram_kgroups(C) * C * C * sizeof(float);
 }
 
+// Launch description of one Gram forward: which kernel (kind as in GramMulti; 3 = one of the generic instantiations), its
+// arguments and grid, and the reduce that follows (slabs to sum, mirror granularity).
+struct GramFwdPlan { GemmArgs g; int kind, gx, gy, TM; bool fast; int red_nsplit, red_tm; };
+
+static GramFwdPlan gram_fwd_plan(const float *feat, int B, int C, int HW, void *workspace, int scale = 1) {
+    GramFwdPlan q;
+    GemmArgs &g = q.g;
+    memset(&g, 0, sizeof(g));
+    g.nsplit = gram_split(B, C, HW, &g.kper, scale);
+    g.A = feat; g.B = feat; g.C = reinterpret_cast<float *>(workspace);
+    g.M = C; g.N = C; g.K = HW; g.lda = HW; g.ldb = HW; g.ldc = C;
+    g.sA = g.sB = (size_t)C * HW;
+    g.sSplit = (size_t)C * C; g.sC = g.sSplit * g.nsplit;
+    g.tri = 1; g.coef = 1.f; g.accumulate = 0;
+    const int TM = q.TM = (C % 128 == 0) ? 128 : 64;
+    g.tiles_m = g.tiles_n = st3d::cdiv(C, TM);
+    q.gx = g.tiles_n * (g.tiles_n + 1) / 2; q.gy = g.nsplit;
+    // whole tiles, whole 32-pixel chunks in every split, 16-byte aligned rows: the branch-free instantiation
+    static const bool allow_fast = [] { const char *e = getenv("ST3D_GRAM_FAST"); return !(e && e[0] == '0'); }();
+    q.fast = allow_fast && C % TM == 0 && HW % 32 == 0 && g.kper % 32 == 0 && (((uintptr_t)feat) & 15) == 0;
+    static const bool tri = [] { const char *e = getenv("ST3D_GRAM_DIAG_TRI"); return !(e && e[0] == '0'); }();
+    q.kind = 3; q.red_nsplit = g.nsplit;
+    if (q.fast && tri && (C == 64 || C == 128)) {     // upper blocks only, waves split the K chunk (gram_diag_kernel)
+        const int KG = gram_kgroups(C);
+        g.sC = g.sSplit * g.nsplit * KG;
+        q.kind = C == 64 ? 0 : 1; q.gx = 1; q.red_nsplit = g.nsplit * KG; q.red_tm = 32;
+        return q;
+    }
+    if (q.fast && g.tiles_n > 1 && TM == 128) q.kind = 2;
+    // mirror granularity: the multi-tile FAST launch leaves the lower-left 64 x 64 of its diagonal tiles unwritten
+    q.red_tm = q.kind == 2 ? 64 : TM;
+    return q;
+}
+
 extern "C" int st3d_gram_fwd(const float *feat, int B, int C, int HW, void *workspace, size_t workspace_bytes, float *gram,
                              st3d_stream_t stream) {
     ST3D_CHECK_ARG(feat && workspace && gram);
     ST3D_CHECK_ARG(B > 0 && C > 0 && HW > 0);
     ST3D_CHECK_ARG(workspace_bytes >= st3d_gram_workspace_bytes(B, C, HW));
     hipStream_t s = st3d::as_stream(stream);
-    GemmArgs g;
-    memset(&g, 0, sizeof(g));
-    g.nsplit = gram_split(B, C, HW, &g.kper);
-    g.A = feat; g.B = feat; g.C = reinterpret_cast<float *>(workspace);
-    g.M = C; g.N = C; g.K = HW; g.lda = HW; g.ldb = HW; g.ldc = C;
-    g.sA = g.sB = (size_t)C * HW;
-    g.sSplit = (size_t)C * C; g.sC = g.sSplit * g.nsplit;
-    g.tri = 1; g.coef = 1.f; g.accumulate = 0;
-    const int TM = (C % 128 == 0) ? 128 : 64;
-    g.tiles_m = g.tiles_n = st3d::cdiv(C, TM);
-    dim3 grid(g.tiles_n * (g.tiles_n + 1) / 2, g.nsplit, B);
-    // whole tiles, whole 32-pixel chunks in every split, 16-byte aligned rows: the branch-free instantiation
-    static const bool allow_fast = [] { const char *e = getenv("ST3D_GRAM_FAST"); return !(e && e[0] == '0'); }();
-    const bool fast = allow_fast && C % TM == 0 && HW % 32 == 0 && g.kper % 32 == 0 && (((uintptr_t)feat) & 15) == 0;
-    static const bool tri = [] { const char *e = getenv("ST3D_GRAM_DIAG_TRI"); return !(e && e[0] == '0'); }();
-    if (fast && tri && (C == 64 || C == 128)) {     // upper blocks only, waves split the K chunk (gram_diag_kernel)
-        const int KG = gram_kgroups(C);
-        g.sC = g.sSplit * g.nsplit * KG;
+    const GramFwdPlan q = gram_fwd_plan(feat, B, C, HW, workspace);
+    const GemmArgs &g = q.g;
+    const int TM = q.TM;
+    const bool fast = q.fast;
+    dim3 grid(q.gx, q.gy, B);
+    if (q.kind <= 1) {
         if (C == 64) gram_diag_kernel<2><<<dim3(1, g.nsplit, B), 256, 0, s>>>(g);
         else gram_diag_kernel<4><<<dim3(1, g.nsplit, B), 256, 0, s>>>(g);
         ST3D_LAUNCH_CHECK();
-        gram_reduce_kernel<<<dim3(st3d::cdiv((long)C * C, 64), B), 256, 0, s>>>(g.C, g.nsplit * KG, C, 32, g.sSplit, g.sC, gram);
+        gram_reduce_kernel<<<dim3(st3d::cdiv((long)C * C, 64), B), 256, 0, s>>>(g.C, q.red_nsplit, C, q.red_tm, g.sSplit, g.sC, gram);
         ST3D_LAUNCH_CHECK();
         return ST3D_OK;
     }
@@ -600,10 +637,104 @@ extern "C" int st3d_gram_fwd(const float *feat, int B, int C, int HW, void *work
     } else if (TM == 128) { if (fast) gemm_kernel<2, 2, 0, 0, 32, true><<<grid, 256, 0, s>>>(g); else gemm_kernel<2, 2, 0><<<grid, 256, 0, s>>>(g); }
     else gemm_kernel<1, 1, 0><<<grid, 256, 0, s>>>(g);
     ST3D_LAUNCH_CHECK();
-    // mirror granularity: the multi-tile FAST launch leaves the lower-left 64 x 64 of its diagonal tiles unwritten
-    const int mirror = (fast && g.tiles_n > 1 && TM == 128) ? 64 : TM;
-    gram_reduce_kernel<<<dim3(st3d::cdiv((long)C * C, 64), B), 256, 0, s>>>(g.C, g.nsplit, C, mirror, g.sSplit, g.sC, gram);
+    gram_reduce_kernel<<<dim3(st3d::cdiv((long)C * C, 64), B), 256, 0, s>>>(g.C, q.red_nsplit, C, q.red_tm, g.sSplit, g.sC, gram);
     ST3D_LAUNCH_CHECK();
+    return ST3D_OK;
+}
+
+// Every style layer's Gram in one launch pair (gram_multi_kernel + gram_reduce_multi_kernel).  items: host array; every
+// item gets its own slab region of `workspace` (st3d_gram_multi_workspace_bytes = the sum), because the layers run
+// concurrently.  Results are bitwise those of st3d_gram_fwd per item (same bodies, same splits, same reduce tree).  Items
+// the fused kernel has no body for (shapes outside the whole-tile fast path) run through st3d_gram_fwd one by one.
+extern "C" size_t st3d_gram_multi_workspace_bytes(const st3d_gram_item *items, int count) {
+    size_t tot = 0;
+    for (int i = 0; items && i < count; ++i)
+        tot += (st3d_gram_workspace_bytes(items[i].B, items[i].C, items[i].HW) + 255) & ~(size_t)255;
+    return tot;
+}
+
+extern "C" int st3d_gram_fwd_multi(const st3d_gram_item *items, int count, void *workspace, size_t workspace_bytes,
+                                   st3d_stream_t stream) {
+    ST3D_CHECK_ARG(items && count > 0 && count <= kMaxGramItems && workspace);
+    ST3D_CHECK_ARG(workspace_bytes >= st3d_gram_multi_workspace_bytes(items, count) && ((uintptr_t)workspace & 255) == 0);
+    hipStream_t s = st3d::as_stream(stream);
+    static const bool fuse = [] { const char *e = getenv("ST3D_GRAM_MULTI"); return !(e && e[0] == '0'); }();
+    // relu1_1-like items (kind 0: one row stream per channel, HBM-bound) are dealt between the blocks of the others
+    static const int deal = [] { const char *e = getenv("ST3D_GRAM_MULTI_DEAL"); return e ? atoi(e) : 0; }();
+    // (read per call, not cached: tests compare scale 1 with st3d_gram_fwd bit for bit)
+    const int scale = [] { const char *e = getenv("ST3D_GRAM_MULTI_SCALE"); const int v = e ? atoi(e) : 2; return v >= 1 && v <= 16 ? v : 2; }();
+    GramMulti gm;
+    ReduceMulti rm;
+    memset(&gm, 0, sizeof(gm));
+    memset(&rm, 0, sizeof(rm));
+    char *ws = static_cast<char *>(workspace);
+    int order[kMaxGramItems], nf = 0;
+    GramFwdPlan plans[kMaxGramItems];
+    size_t woff[kMaxGramItems];
+    size_t off = 0;
+    for (int i = 0; i < count; ++i) {
+        const st3d_gram_item &it = items[i];
+        ST3D_CHECK_ARG(it.feat && it.gram && it.B > 0 && it.C > 0 && it.HW > 0);
+        woff[i] = off;
+        int sc = scale;
+        if (const char *e = getenv("ST3D_GRAM_MULTI_SCALES")) {        // tuning knob (tools/gram_multi_sweep.py): "c64,c128,c256,c512"
+            int v[4] = {scale, scale, scale, scale};
+            sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]);
+            sc = it.C <= 64 ? v[0] : (it.C <= 128 ? v[1] : (it.C <= 256 ? v[2] : v[3]));
+            if (sc < 1 || sc > 16) sc = scale;
+        }
+        plans[i] = gram_fwd_plan(it.feat, it.B, it.C, it.HW, ws + off, fuse ? sc : 1);
+        if (plans[i].kind > 2) plans[i] = gram_fwd_plan(it.feat, it.B, it.C, it.HW, ws + off, 1);      // (runs through st3d_gram_fwd below)
+        off += (st3d_gram_workspace_bytes(it.B, it.C, it.HW) + 255) & ~(size_t)255;
+    }
+    // fused items: the dealt-in one (first kind-0 item) goes to slot 0, the rest by descending work per block
+    int dealt = -1;
+    for (int i = 0; i < count && deal; ++i)
+        if (fuse && plans[i].kind == 0 && dealt < 0) dealt = i;
+    if (dealt >= 0) order[nf++] = dealt;
+    for (int i = 0; i < count; ++i)
+        if (fuse && plans[i].kind <= 2 && i != dealt) order[nf++] = i;
+    const int rest0 = dealt >= 0 ? 1 : 0;
+    for (int a = rest0; a < nf; ++a)          // (insertion sort, <= 8 items) blocks with the longest K range first
+        for (int b = a + 1; b < nf; ++b) {
+            auto work = [&](int i) { return (long)plans[i].g.kper * (plans[i].kind == 0 ? 3 : plans[i].kind == 1 ? 10 : 16); };
+            if (work(order[b]) > work(order[a])) { const int t = order[a]; order[a] = order[b]; order[b] = t; }
+        }
+    if (nf > 0) {
+        int restblocks = 0;
+        for (int k = 0; k < nf; ++k) {
+            const GramFwdPlan &q = plans[order[k]];
+            gm.g[k] = q.g; gm.kind[k] = q.kind; gm.gx[k] = q.gx; gm.gy[k] = q.gy;
+            const int blocks = q.gx * q.gy * items[order[k]].B;
+            if (k == 0 && dealt >= 0) { gm.n0 = blocks; gm.first[0] = 0; continue; }
+            gm.first[k] = restblocks;
+            restblocks += blocks;
+        }
+        gm.first[nf] = restblocks;
+        gm.n_items = nf;
+        const int total = gm.n0 + restblocks;
+        gm.stride = (dealt >= 0 && gm.n0 > 0) ? (total / gm.n0 > 0 ? total / gm.n0 : 1) : 0;
+        if (restblocks == 0) gm.stride = gm.n0 > 0 ? 1 : 0;
+        gram_multi_kernel<<<total, 256, 0, s>>>(gm);
+        ST3D_LAUNCH_CHECK();
+        int rblocks = 0;
+        for (int k = 0; k < nf; ++k) {
+            const int i = order[k];
+            const GramFwdPlan &q = plans[i];
+            const int bpi = (int)st3d::cdiv((long)items[i].C * items[i].C, 64);
+            rm.r[k] = ReduceItem{q.g.C, items[i].gram, q.red_nsplit, items[i].C, q.red_tm, bpi, q.g.sSplit, q.g.sC};
+            rm.first[k] = rblocks;
+            rblocks += bpi * items[i].B;
+        }
+        rm.first[nf] = rblocks; rm.n_items = nf;
+        gram_reduce_multi_kernel<<<rblocks, 256, 0, s>>>(rm);
+        ST3D_LAUNCH_CHECK();
+    }
+    for (int i = 0; i < count; ++i)
+        if (!(fuse && plans[i].kind <= 2)) {
+            const st3d_gram_item &it = items[i];
+            ST3D_TRY(st3d_gram_fwd(it.feat, it.B, it.C, it.HW, ws + woff[i], st3d_gram_workspace_bytes(it.B, it.C, it.HW), it.gram, stream));
+        }
     return ST3D_OK;
 }
 

@@ -356,7 +356,13 @@ extern "C" int st3d_plan_create(st3d_plan **out, st3d_vgg *vgg, int B, int S) {
         rc = dev_alloc(p, &p->style_gram[i], cc);
         if (rc == ST3D_OK) rc = dev_alloc(p, &p->gram[i], cc);
         if (rc == ST3D_OK) rc = dev_alloc(p, &p->D[i], cc);
-        const size_t ws = st3d_gram_workspace_bytes(B, p->C[m], p->H[m] * p->W[m]);
+    }
+    // every style layer has its own split-K slab region: the five Grams of a step run as ONE launch (st3d_gram_fwd_multi).
+    // Sized for the worst batch 1..B (the split count is rounded per batch size, so n < B can need a little more than B).
+    for (int n = 1; n <= B && rc == ST3D_OK; ++n) {
+        st3d_gram_item items[5];
+        for (int i = 0; i < 5; ++i) items[i] = st3d_gram_item{nullptr, nullptr, n, p->C[kStyleTap[i]], p->H[kStyleTap[i]] * p->W[kStyleTap[i]]};
+        const size_t ws = st3d_gram_multi_workspace_bytes(items, 5);
         if (ws > wsmax) wsmax = ws;
     }
     p->gram_ws_bytes = wsmax;
@@ -444,15 +450,26 @@ extern "C" int st3d_plan_set_content_features(st3d_plan *p, const float *feat, i
     return ST3D_OK;
 }
 
+// the five style taps' Grams (of the n images of the last forward) in one launch pair
+static int grams_of_taps(st3d_plan *p, int n, float *const *out, hipStream_t s) {
+    st3d_gram_item items[5];
+    for (int i = 0; i < 5; ++i) {
+        const int m = kStyleTap[i];
+        items[i] = st3d_gram_item{p->act[m], out[i], n, p->C[m], p->H[m] * p->W[m]};
+    }
+    return st3d_gram_fwd_multi(items, 5, p->gram_ws, p->gram_ws_bytes, s);
+}
+
 extern "C" int st3d_plan_set_style(st3d_plan *p, const float *style, int style_batch, int n, st3d_stream_t stream) {
     ST3D_CHECK_ARG(p && style && n > 0 && n <= p->B && (style_batch == 1 || style_batch == n));
     hipStream_t s = st3d::as_stream(stream);
     ST3D_TRY(forward(p, style, style_batch, 28, false, s));
-    for (int i = 0; i < 5; ++i) {
-        const int m = kStyleTap[i];
+    {
         Scope sc(p, F_GRAM_FWD, s);
-        ST3D_TRY(st3d_gram_fwd(p->act[m], style_batch, p->C[m], p->H[m] * p->W[m], p->gram_ws, p->gram_ws_bytes,
-                               p->style_gram[i], s));
+        ST3D_TRY(grams_of_taps(p, style_batch, p->style_gram, s));
+    }
+    if (p->style_batch != style_batch && p->gexec) {       // a captured loss step indexes the style Grams with the old batch stride
+        (void)hipGraphExecDestroy(p->gexec); p->gexec = nullptr; p->gkey.warm = 0;
     }
     p->style_batch = style_batch;
     p->have_style = true;
@@ -534,13 +551,13 @@ static int plan_loss_enqueue(st3d_plan *p, const float *current, int n, int batc
     items[0] = st3d_sqdiff_item{p->act[mc], p->content_target, nullptr, (size_t)n * chw, (size_t)n * chw,
                                 (float)(1.0 / (bd * (double)chw)), 1};
     float style_coef[5];
+    {
+        Scope sc(p, F_GRAM_FWD, s);
+        ST3D_TRY(grams_of_taps(p, n, p->gram, s));
+    }
     for (int i = 0; i < 5; ++i) {
         const int m = kStyleTap[i];
         const double C = p->C[m], Hh = p->H[m];
-        {
-            Scope sc(p, F_GRAM_FWD, s, m);
-            ST3D_TRY(st3d_gram_fwd(p->act[m], n, p->C[m], p->H[m] * p->W[m], p->gram_ws, p->gram_ws_bytes, p->gram[i], s));
-        }
         const size_t cc = (size_t)p->C[m] * p->C[m];
         const double norm = 1.0 / (bd * C * C) / (C * C * Hh * Hh);
         items[1 + i] = st3d_sqdiff_item{p->gram[i], p->style_gram[i], p->D[i], (size_t)n * cc,

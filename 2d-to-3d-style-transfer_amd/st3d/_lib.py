@@ -76,6 +76,8 @@ SIGNATURES = {
     "st3d_maxpool2x2_fwd": (c_int, [c_f32p, c_f32p, c_u8p, c_int, c_int, c_int, c_int, c_stream]),
     "st3d_gram_workspace_bytes": (c_size, [c_int, c_int, c_int]),
     "st3d_gram_fwd": (c_int, [c_f32p, c_int, c_int, c_int, ctypes.c_void_p, c_size, c_f32p, c_stream]),
+    "st3d_gram_multi_workspace_bytes": (c_size, [ctypes.c_void_p, c_int]),
+    "st3d_gram_fwd_multi": (c_int, [ctypes.c_void_p, c_int, ctypes.c_void_p, c_size, c_stream]),
     "st3d_gram_bwd": (c_int, [c_f32p, c_f32p, c_int, c_int, c_int, c_float, c_int, c_f32p, c_stream]),
     "st3d_gram_bwd_gated": (c_int, [c_f32p, c_f32p, c_int, c_int, c_int, c_float, c_int, c_f32p, c_stream]),
     "st3d_reduce_partials": (c_int, []),

@@ -416,6 +416,24 @@ def gram_fwd(feat):
     return g
 
 
+class _GramItem(ctypes.Structure):
+    _fields_ = [("feat", ctypes.c_void_p), ("gram", ctypes.c_void_p), ("B", ctypes.c_int), ("C", ctypes.c_int), ("HW", ctypes.c_int)]
+
+
+def gram_fwd_multi(feats):
+    """[(B,C,H,W) ...] -> [(B,C,C) ...]: the Grams of several layers in one launch pair (st3d_gram_fwd_multi)."""
+    feats = [f.contiguous() for f in feats]
+    grams = [torch.empty((f.shape[0], f.shape[1], f.shape[1]), dtype=F32, device=f.device) for f in feats]
+    items = (_GramItem * len(feats))()
+    for it, f, g in zip(items, feats, grams):
+        it.feat, it.gram, it.B, it.C, it.HW = dptr(f, F32), dptr(g, F32), f.shape[0], f.shape[1], f[0, 0].numel()
+    nb = _lib.load().st3d_gram_multi_workspace_bytes(items, len(feats))
+    ws = torch.empty((max(nb // 4, 64),), dtype=F32, device=feats[0].device)
+    assert ws.data_ptr() % 256 == 0
+    call("st3d_gram_fwd_multi", items, len(feats), dptr(ws), nb, stream_ptr())
+    return grams
+
+
 def gram_bwd(D, feat, coef, out=None, gated=False):
     """out (+)= coef * D feat; gated: then zeroed where feat <= 0 (st3d_gram_bwd_gated)."""
     B, C = feat.shape[:2]

@@ -62,6 +62,8 @@ def conv_alg_flops(module, S, B):
 
 
 def gram_alg_flops(module, S, B):
+    if module not in STYLE_TAPS:        # the one launch pair that holds all five style layers (st3d_gram_fwd_multi)
+        return sum(gram_alg_flops(m, S, B) for m in STYLE_TAPS)
     C, d = STYLE_TAPS[module]
     return 2.0 * C * C * (S // d) ** 2 * B
 
@@ -70,9 +72,17 @@ def gram_fwd_issued_fraction(module):
     """MFMA work the Gram forward ISSUES over the full C x C product (gram.hip): only blocks on or above the diagonal
     exist -- 32x32 blocks in gram_diag_kernel (C = 64: 3 of 4, C = 128: 10 of 16), 64x64 wave tiles in the multi-tile
     launches (the mirror wave of a diagonal 128x128 tile sits the MFMAs out: C = 256 10 of 16, C = 512 36 of 64)."""
+    if module not in STYLE_TAPS:        # all five layers in one launch: flop-weighted over the layers (needs S, B: see caller)
+        raise KeyError(module)
     C = STYLE_TAPS[module][0]
     n = C // 32 if C <= 128 else C // 64
     return (n * (n + 1) / 2) / (n * n)
+
+
+def gram_fwd_issued_flops(module, S, B):
+    if module not in STYLE_TAPS:
+        return sum(gram_fwd_issued_flops(m, S, B) for m in STYLE_TAPS)
+    return gram_alg_flops(module, S, B) * gram_fwd_issued_fraction(module)
 
 
 def check_fractions(obj, path="line"):
@@ -332,7 +342,7 @@ def main():
                 alg = issued = conv_alg_flops(module, S, Bv)          # direct MFMA kernels (ST3D_CONV=direct, odd shapes)
             elif fam == "gram_fwd":
                 alg = gram_alg_flops(module, S, Bv)
-                issued = alg * gram_fwd_issued_fraction(module)
+                issued = gram_fwd_issued_flops(module, S, Bv)
             elif fam == "gram_bwd":
                 alg = issued = gram_alg_flops(module, S, Bv)
                 C, d = STYLE_TAPS[module]
@@ -399,7 +409,7 @@ def main():
         if args.no_hoist:
             f_wino_alg += sum(conv_alg_flops(m, S, Bv) for m, *_ in CONVS if 0 < m <= 21)
         f_issued_step = (f_wino_alg * (16.0 / 36.0) if wino else f_wino_alg + 2 * conv_alg_flops(0, S, Bv)) \
-            + sum(gram_alg_flops(m, S, Bv) * (gram_fwd_issued_fraction(m) + 1.0) for m in STYLE_TAPS)
+            + sum(gram_fwd_issued_flops(m, S, Bv) + gram_alg_flops(m, S, Bv) for m in STYLE_TAPS)
         if os.environ.get("ST3D_TAP0_FUSED") != "0":
             f_issued_step += 2.0 * 32 * 64 * S * S * Bv        # conv1_1's input gradient as an MFMA product (csrc/tap0.hip)
         step_s = dev_ms / args.steps * 1e-3

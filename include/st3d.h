@@ -231,6 +231,19 @@ size_t st3d_gram_workspace_bytes(int B, int C, int HW);
  * (deterministic) slab reduction. */
 int st3d_gram_fwd(const float *feat, int B, int C, int HW, void *workspace, size_t workspace_bytes,
                   float *gram, st3d_stream_t stream);
+/* The Grams of ALL style layers of a step (losses.py:34-37 loops over them; style_transfer.py:47-49,
+ * 66-69 likewise) in one launch pair: items is a HOST array (<= 8), every item is one
+ * st3d_gram_fwd problem; workspace >= st3d_gram_multi_workspace_bytes(items, count), 256-byte
+ * aligned (each layer has its own slab region: they run concurrently).  Bitwise the results of
+ * st3d_gram_fwd per item.  ST3D_GRAM_MULTI=0 runs the items one by one (A/B). */
+typedef struct st3d_gram_item {
+    const float *feat;   /* (B, C, HW) */
+    float *gram;         /* (B, C, C) */
+    int B, C, HW;
+} st3d_gram_item;
+size_t st3d_gram_multi_workspace_bytes(const st3d_gram_item *items, int count);
+int st3d_gram_fwd_multi(const st3d_gram_item *items, int count, void *workspace, size_t workspace_bytes,
+                        st3d_stream_t stream);
 /* gfeat (B,C,HW) (+)= coef * (D F) with D (B,C,C) symmetric (D = G - S); accumulate != 0 adds
  * into gfeat. */
 int st3d_gram_bwd(const float *D, const float *feat, int B, int C, int HW, float coef,

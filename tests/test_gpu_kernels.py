@@ -356,6 +356,44 @@ def test_vertex_path_backward_matches_oracle(dev, ops, cow):
     assert only[0] is None and torch.equal(only[1], gbary)
 
 
+def test_gram_forward_of_all_layers_in_one_launch_is_bitwise_the_per_layer_result(dev, ops, monkeypatch):
+    """st3d_gram_fwd_multi (round 3: one launch pair for the five style layers of a step instead of ten launches): same
+    kernel bodies and the same fixed reduce tree as st3d_gram_fwd, so with the same split counts (ST3D_GRAM_MULTI_SCALE=1,
+    set by the fixture below) the results are bit-identical per layer; VGG shapes at 64^2 with 3 images (a batch the split
+    counts are not tuned for), plus two shapes outside the whole-tile fast path (C = 96; HW not a multiple of 32), which
+    fall back to the per-layer launches inside the same call.  The default (fewer, longer splits: half the slab traffic)
+    is checked against fp64 and for run-to-run bitwise reproducibility in the test after this one."""
+    monkeypatch.setenv("ST3D_GRAM_MULTI_SCALE", "1")
+    g = torch.Generator().manual_seed(5)
+    shapes = [(3, 64, 64, 64), (3, 128, 32, 32), (3, 256, 16, 16), (3, 512, 8, 8), (3, 512, 4, 4), (2, 96, 16, 16), (1, 64, 5, 7)]
+    feats = [torch.randn(sh, generator=g).clamp_min(0).to(dev) for sh in shapes]
+    multi = ops.gram_fwd_multi(feats)
+    for f, gm in zip(feats, multi):
+        single = ops.gram_fwd(f)
+        assert torch.equal(gm, single), f.shape
+        ref = torch.bmm(f.double().flatten(2), f.double().flatten(2).transpose(1, 2))
+        assert float((gm.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+        assert torch.equal(gm, gm.transpose(1, 2))
+    # the five layers alone (what the loss plan launches), full VGG depth at 128^2, batch 2; and a lone relu1_1-like item
+    feats = [torch.randn(sh, generator=g).clamp_min(0).to(dev) for sh in
+             [(2, 64, 128, 128), (2, 128, 64, 64), (2, 256, 32, 32), (2, 512, 16, 16), (2, 512, 8, 8)]]
+    for fs in (feats, feats[:1], feats[1:]):
+        for f, gm in zip(fs, ops.gram_fwd_multi(fs)):
+            assert torch.equal(gm, ops.gram_fwd(f)), f.shape
+
+
+def test_gram_forward_multi_default_splits_are_reproducible_and_exact_to_fp32(dev, ops):
+    g = torch.Generator().manual_seed(6)
+    feats = [torch.randn(sh, generator=g).clamp_min(0).to(dev) for sh in
+             [(4, 64, 256, 256), (4, 128, 128, 128), (4, 256, 64, 64), (4, 512, 32, 32), (4, 512, 16, 16)]]
+    a = ops.gram_fwd_multi(feats)
+    b = ops.gram_fwd_multi(feats)
+    for f, ga, gb in zip(feats, a, b):
+        assert torch.equal(ga, gb) and torch.equal(ga, ga.transpose(1, 2))
+        ref = torch.bmm(f.double().flatten(2), f.double().flatten(2).transpose(1, 2))
+        assert float((ga.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
 def test_mesh_regularisers_match_oracle(dev, ops, cow):
     """values within 1e-5 relative and gradient within 1e-4 relative L2 of the torch-fp64 restatement
     (autograd) on the cow mesh with perturbed vertices; topology counts checked."""
