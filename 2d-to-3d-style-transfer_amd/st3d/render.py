@@ -302,7 +302,8 @@ class _RenderFn(torch.autograd.Function):
             raise NotImplementedError("square texture maps only (the reference resizes to size x size)")
         uvs = verts_uvs.detach().to(torch.float32).reshape(-1, 2).contiguous()
         ndc = ops.project_verts(v, R, T)
-        frag = ops.raster_fwd(ndc, faces_i32, S, z_clip=RasterizationSettings.Z_CLIP_DEFAULT)
+        # (no near-plane watch here: render_views has looked at the vertices' depths before choosing these kernels)
+        frag = ops.raster_fwd(ndc, faces_i32, S)
         rgb, mask = ops.shade_fwd(frag, uvs, faces_uvs_i32, tex)
         ctx.frag, ctx.uvs, ctx.fuv, ctx.tex = frag, uvs, faces_uvs_i32, tex
         ctx.tex_shape = tex_map.shape

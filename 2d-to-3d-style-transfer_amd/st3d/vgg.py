@@ -119,8 +119,8 @@ class Vgg19Features:
     MAX_PLANS = int(os.environ.get("ST3D_MAX_PLANS", "4"))
 
     def plan(self, B, S):
-        """The (cached) workspace for batch B at SxS.  A plan holds every activation of its shape (9 GB for 8 views at
-        512^2, 72 GB for 16 at 1024^2), so at most MAX_PLANS shapes stay resident, least recently used first out; a
+        """The (cached) workspace for batch B at SxS.  A plan holds every activation of its shape (4.4 GB for 8 views at
+        512^2, 35 GB for 16 at 1024^2: st3d_plan_bytes), so at most MAX_PLANS shapes stay resident, least recently used first out; a
         plan that does not fit is retried once after the others are released.  An evicted shape is rebuilt on its next
         use (targets are re-derived from the tensors the caller passes, see set_content / set_style)."""
         key = (int(B), int(S))

@@ -183,7 +183,17 @@ def main():
     ap.add_argument("--layers", action="store_true", help="add the per-layer table to the JSON line")
     ap.add_argument("--target", choices=["texture", "mesh", "both"], default="texture",
                     help="optimization_target (BASELINE configs[1] = texture; configs[4] = both)")
+    ap.add_argument("--approach", choices=["second", "first_a", "first_b"], default="second",
+                    help="second: the 3-D loop of second_approach.py:145-190 (the headline).  first_a / first_b: the two phases "
+                         "of first_approach.py -- A = the style_transfer() loop on the pixels of the views (style_transfer.py:59-83, "
+                         "VGG only), B = render -> masked MSE -> texture scatter -> Adam (first_approach.py:191-217, no VGG)")
+    ap.add_argument("--background", choices=["white", "noise"], default="white",
+                    help="content_background and current_background of the reference's CLIs.  noise (notes.txt:1 of the "
+                         "reference: the recommended setting) draws fresh U[0,1) backgrounds every step (utils.py:22), so the "
+                         "content features cannot be hoisted: one more VGG forward to conv4_2 per step")
     args = ap.parse_args()
+    if args.approach != "second" and (args.gpus > 1 or args.background != "white" or args.no_hoist):
+        raise SystemExit("bench.py: --approach first_a / first_b are single-GPU variants with the default backgrounds")
 
     from st3d import launch as st3d_launch
     if not st3d_launch.under_launcher():
@@ -231,24 +241,70 @@ def main():
                    "mesh_laplacian_smoothing_weight": 1.0, "mesh_normal_consistency_weight": 1.0}   # second_approach.py:33-37
     style_tensors = style_image.expand(Bv, -1, -1, -1)
 
-    def content_targets():
+    bg = args.background
+    if bg == "noise":
+        torch.manual_seed(1 + rank)             # the noise backgrounds (torch.rand inside utils.apply_background)
+
+    def content_render():
         with torch.no_grad():
-            c, cm = U.render_meshes(renderer, content_mesh, my_cams)
-            return U.apply_background(c, cm, background_type="white", background=style_tensors)
+            return U.render_meshes(renderer, content_mesh, my_cams)
+
+    content_rgb, content_cov = content_render()         # loop-invariant: cameras and content mesh never change
+
+    def content_targets():
+        c, cm = (content_rgb, content_cov) if not args.no_hoist else content_render()
+        with torch.no_grad():
+            return U.apply_background(c, cm, background_type=bg, background=style_tensors)   # white: identity; noise: fresh draw
 
     content_tensors = content_targets()
+    content_each_step = args.no_hoist or bg == "noise"  # the content VGG forward to conv4_2 cannot be (or is not) hoisted
 
-    def step():
+    def step_second():          # second_approach.py:145-190
         optimizer.zero_grad()
-        content = content_tensors if not args.no_hoist else content_targets()
+        content = content_tensors if not content_each_step else content_targets()
         mesh = U.build_mesh(out["verts_uvs"], out["faces_uvs"], texture_map, out["verts"], out["faces"])
         cur, masks = U.render_meshes(renderer, mesh, my_cams)
-        cur = U.apply_background(cur, masks, background_type="white", background=style_tensors)
+        cur = U.apply_background(cur, masks, background_type=bg, background=style_tensors)
         loss = L.compute_second_approach_loss(cur, content, style_tensors, vgg, 1e6, 1.0, out["verts"], verts, mesh,
                                               reg_weights, args.target, batch_denom=global_views)
         loss.backward()
         optimizer.step()
         return loss
+
+    # first_approach.py phase A = style_transfer(init = content renders, content, style, vgg, steps, lr): the loop body of
+    # the drop-in style_transfer() (2d-to-3d-style-transfer_amd/style_transfer.py: plan.loss + fused Adam on the pixels;
+    # reference style_transfer.py:59-83), its one-time targets (reference :44-51) computed before the timed region
+    if args.approach == "first_a":
+        plan_a = vgg.plan(Bv, S)
+        plan_a.set_content(content_tensors, force=True)
+        plan_a.set_style(style_tensors, Bv, force=True)
+        pixels = content_tensors.clone().detach().contiguous().requires_grad_(True)
+        opt_a = st3d_optim.Adam([pixels], lr=0.01, reduce_grads=False)         # first_approach.py:33 style_transfer_lr
+        optimizer = opt_a
+
+    def step_first_a():
+        lossbuf, grad = plan_a.loss(pixels, 1e6, 1.0)
+        pixels.grad = grad
+        opt_a.step()
+        return lossbuf[0]
+
+    # first_approach.py phase B (:191-217): fit the texture to fixed stylised views through the renderer; the targets here
+    # are the content renders pushed towards the style image (any fixed images do: the loss is a masked MSE)
+    if args.approach == "first_b":
+        targets_b = (0.5 * content_tensors + 0.5 * style_tensors).clamp(0, 1).contiguous()
+
+    def step_first_b():
+        optimizer.zero_grad()
+        mesh = U.build_mesh(out["verts_uvs"], out["faces_uvs"], texture_map, out["verts"], out["faces"])
+        rendered, cov = U.render_meshes(renderer, mesh, my_cams)
+        loss = L.compute_first_approach_loss(rendered=rendered, masks=cov, target_rendered=targets_b, verts=out["verts"],
+                                             target_verts=verts, mesh=mesh, weights=reg_weights, opt_type=args.target,
+                                             batch_denom=global_views)
+        loss.backward()
+        optimizer.step()
+        return loss
+
+    step = {"second": step_second, "first_a": step_first_a, "first_b": step_first_b}[args.approach]
 
     def barrier():
         if world > 1:
@@ -303,14 +359,16 @@ def main():
     if args.profile_kernels or world == 1:
         # per-launch HIP events (recorded by libst3d on the stream the kernels are launched on) over nprof further
         # steps of the same loop, right after the timed region
-        plan = vgg.plan(Bv, S)
-        plan.profile(True)
-        for _ in range(nprof):
-            step()
-        torch.cuda.synchronize()
-        launches = plan.profile_launches()
-        plan.profile_read()
-        plan.profile(False)
+        launches = []
+        if args.approach != "first_b":          # (phase B of the first approach has no VGG plan)
+            plan = vgg.plan(Bv, S)
+            plan.profile(True)
+            for _ in range(nprof):
+                step()
+            torch.cuda.synchronize()
+            launches = plan.profile_launches()
+            plan.profile_read()
+            plan.profile(False)
         agg = {}
         for fam, module, ms in launches:
             e = agg.setdefault((fam, module), [0.0, 0])
@@ -371,6 +429,7 @@ def main():
                 k["hbm_frac"] = round(nbytes / (ms * 1e-3) / PEAK_HBM, 4)
         # the HBM/latency-bound kernels outside the VGG plan, each timed alone on this rank's inputs (torch events on the
         # current stream, which is the stream libst3d launches them on); algorithmic bytes per SURVEY.md 8d
+        hb = {}
         with torch.no_grad():
             mesh = U.build_mesh(out["verts_uvs"], out["faces_uvs"], texture_map, out["verts"], out["faces"])
             f32 = mesh.faces_i32()
@@ -382,14 +441,32 @@ def main():
             frag = ops.raster_fwd(ndc, f32, S)
             gimg = torch.randn((Bv, 3, S, S), device=device)
             st = optimizer._state_of(texture_map) if any(q is texture_map for q in optimizer.params) else None
-            hb = {
+            hb = {} if args.approach == "first_a" else {
                 "raster_fwd": (time_ms(lambda: ops.raster_fwd(ndc, f32, S)), Bv * Fn * 52.0 + px * 24.0),
                 "shade_fwd": (time_ms(lambda: ops.shade_fwd(frag, vuv, fuv, tex2)), px * (24.0 + 16.0)),
                 "shade_bwd_texture_scatter": (time_ms(lambda: ops.shade_bwd(gimg, frag, vuv, fuv, tex2)), px * (24.0 + 12.0) + 2 * tex2.numel() * 4.0),
             }
-            ops.set_deterministic(False)
-            hb["shade_bwd_texture_scatter_float_atomics"] = (time_ms(lambda: ops.shade_bwd(gimg, frag, vuv, fuv, tex2)), px * (24.0 + 12.0) + 2 * tex2.numel() * 4.0)
-            ops.set_deterministic(True)
+            if hb:
+                ops.set_deterministic(False)
+                hb["shade_bwd_texture_scatter_float_atomics"] = (time_ms(lambda: ops.shade_bwd(gimg, frag, vuv, fuv, tex2)), px * (24.0 + 12.0) + 2 * tex2.numel() * 4.0)
+                ops.set_deterministic(True)
+            if args.approach == "first_b":      # losses.py:71-75: reads rendered, target (3 channels each) and the mask, writes the gradient
+                rend = torch.rand((Bv, 3, S, S), device=device)
+                mk = (frag[0] >= 0).to(torch.float32)[:, None].contiguous()
+                hb["masked_mse"] = (time_ms(lambda: ops.masked_mse(rend, targets_b, mk)), px * (12.0 + 12.0 + 4.0 + 12.0))
+            if hb and args.target != "texture":
+                # the vertex path of 'mesh' / 'both' (SURVEY.md K14, K15): d/d(barycentrics) out of the shade backward ->
+                # raster backward (fixed-point scatter over B x V x 3) -> projection backward; the four mesh regularisers
+                from st3d import mesh_losses as ML
+                _, gbary = ops.shade_bwd(gimg, frag, vuv, fuv, tex2, want_bary=True)
+                gndc = ops.raster_bwd(gbary, frag[0], ndc, f32)
+                topo = ML._topology(mesh)
+                vd = out["verts"].detach()
+                hb["shade_bwd_with_bary"] = (time_ms(lambda: ops.shade_bwd(gimg, frag, vuv, fuv, tex2, want_bary=True)),
+                                             px * (24.0 + 12.0 + 12.0) + 2 * tex2.numel() * 4.0)
+                hb["raster_bwd_vertex_scatter"] = (time_ms(lambda: ops.raster_bwd(gbary, frag[0], ndc, f32)), px * (12.0 + 4.0) + Bv * Fn * 48.0)
+                hb["project_verts_bwd"] = (time_ms(lambda: ops.project_verts_bwd(vd, my_cams.R, my_cams.T, gndc)), Bv * vd.shape[0] * 12.0 * 2)
+                hb["mesh_regularisers"] = (time_ms(lambda: ops.mesh_reg(vd, verts, topo, [1.0, 1.0, 1.0, 1.0])), vd.shape[0] * 12.0 * 8)
             if st is not None:
                 gdummy = torch.zeros_like(tex2)
                 pdummy, m1, m2 = tex2.clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone()
@@ -403,17 +480,18 @@ def main():
         s2 = (S / 512.0) ** 2
         # algorithmic and issued MFMA flops of one step on this GPU
         f_alg_step = sum(conv_alg_flops(m, S, Bv) for m, *_ in CONVS) * 2 + sum(gram_alg_flops(m, S, Bv) for m in STYLE_TAPS) * 2
-        if args.no_hoist:
+        if content_each_step:
             f_alg_step += sum(conv_alg_flops(m, S, Bv) for m, *_ in CONVS if m <= 21)
         f_wino_alg = sum(conv_alg_flops(m, S, Bv) for m, *_ in CONVS if m != 0) * 2
-        if args.no_hoist:
+        if content_each_step:
             f_wino_alg += sum(conv_alg_flops(m, S, Bv) for m, *_ in CONVS if 0 < m <= 21)
         f_issued_step = (f_wino_alg * (16.0 / 36.0) if wino else f_wino_alg + 2 * conv_alg_flops(0, S, Bv)) \
             + sum(gram_fwd_issued_flops(m, S, Bv) + gram_alg_flops(m, S, Bv) for m in STYLE_TAPS)
         if os.environ.get("ST3D_TAP0_FUSED") != "0":
             f_issued_step += 2.0 * 32 * 64 * S * S * Bv        # conv1_1's input gradient as an MFMA product (csrc/tap0.hip)
         step_s = dev_ms / args.steps * 1e-3
-        std_cfg = S == 512 and Bv == 8 and not args.no_hoist and wino and args.mesh == "cow" and args.target == "texture"
+        std_cfg = (S == 512 and Bv == 8 and not content_each_step and wino and args.mesh == "cow" and args.target == "texture"
+                   and args.approach == "second")
         traffic, tpath = {}, ""
         if std_cfg:
             import glob
@@ -459,21 +537,54 @@ def main():
                         "HIP-event time on the launch stream over %d steps after the timed region; frac = matrix-pipe "
                         "utilisation.  alg_equiv_tflops = the direct-convolution count over the same time (may exceed the "
                         "peak; it is not a roofline fraction)." % (f_conv_issued / 1e9, f_conv_alg / 1e9, nprof)}
+        if args.approach == "first_b" and kernels:
+            # phase B of the first approach has no VGG: the step IS the HBM/latency-bound render + scatter kernels.  Its
+            # roofline is HBM: algorithmic bytes of SURVEY.md 8d per kernel over the kernel's own (standalone, back-to-back)
+            # time; the dominant one is the rasteriser.  step_roofline prices all of them over the measured step, host gaps included.
+            names = [k for k in ("raster_fwd", "shade_fwd", "masked_mse",
+                                  "shade_bwd_with_bary" if "shade_bwd_with_bary" in kernels else "shade_bwd_texture_scatter",
+                                  "raster_bwd_vertex_scatter", "project_verts_bwd", "mesh_regularisers", "adam") if k in kernels]
+            kb = {k: kernels[k]["alg_gbps"] * 1e9 * kernels[k]["ms_per_call"] * 1e-3 for k in names}
+            ksum_ms = sum(kernels[k]["ms_per_call"] for k in names)
+            dom = max(names, key=lambda k: kernels[k]["ms_per_call"])
+            step_roofline = {"bound": "hbm", "achieved": round(sum(kb.values()) / step_s / 1e9, 1), "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+                             "frac": round(sum(kb.values()) / step_s / PEAK_HBM, 4), "traffic": None,
+                             "kernel_ms_sum_standalone": round(ksum_ms, 4), "device_ms_per_step": round(step_s * 1e3, 4),
+                             "host_or_launch_bound_share": round(max(0.0, 1.0 - ksum_ms / (step_s * 1e3)), 3),
+                             "note": "algorithmic bytes of the step's kernels (%s) over the HIP-event time of the timed region; "
+                                     "the difference between that time and the kernels' standalone sum is launch / host time "
+                                     "(Python autograd + ~12 launches per step)" % ", ".join(names)}
+            roofline = {"bound": "hbm", "kernel": dom + " (csrc/raster.hip: face setup + coarse bins + 16x16-pixel tiles)" if dom == "raster_fwd" else dom,
+                        "achieved": kernels[dom]["alg_gbps"], "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": kernels[dom]["hbm_frac"],
+                        "traffic": None, "avg_launch_ms": kernels[dom]["ms_per_call"],
+                        "note": "the longest kernel of a phase-B step, timed alone on this step's inputs; latency-bound "
+                                "(tile lists, per-pixel face walks), not a stream"}
         tgt = {"texture": "texture-only optimisation", "mesh": "vertex optimisation", "both": "joint vertex + texture optimisation"}[args.target]
         cfg_name = "BASELINE.json configs[1]" if std_cfg else "variant of BASELINE.json configs[1]"
+        loop = {"second": "second_approach loop body", "first_a": "first_approach phase A = style_transfer() loop on the views' pixels, no renderer",
+                "first_b": "first_approach phase B = render + masked MSE + texture scatter + Adam, no VGG"}[args.approach]
+        unit = {"second": "iter/s (one iter = 8 views of %dx%d: render + VGG-19 fwd/bwd + Gram/content loss + Adam)",
+                "first_a": "iter/s (one iter = one style_transfer() step on 8 images of %dx%d: VGG-19 fwd/bwd + Gram/content loss + Adam on the pixels)",
+                "first_b": "iter/s (one iter = one masked-MSE fitting step on 8 views of %dx%d: render + loss + texture scatter + Adam)"}[args.approach]
+        metric = "style-transfer iters/sec (512x512, 8 views, cow_mesh)"
+        if args.approach != "second":
+            metric = "first_approach phase %s steps/sec (512x512, 8 views, cow_mesh)" % args.approach[-1].upper()
+        hoisted = ("content renders + content features + style Grams" if not content_each_step else
+                   "style Grams + content renders; content features recomputed every step (fresh noise background)" if not args.no_hoist
+                   else "style Grams only (--no-hoist: content re-rendered and its VGG forward redone every step)")
         res = {
-            "metric": "style-transfer iters/sec (512x512, 8 views, cow_mesh)",
+            "metric": metric,
             "value": round(args.steps * world * (Bv / 8.0) / elapsed, 4),
-            "unit": "iter/s (one iter = 8 views of %dx%d: render + VGG-19 fwd/bwd + Gram/content loss + Adam)" % (S, S),
+            "unit": unit % (S, S),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "median_ms_per_step": round(median_ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic views (seeded cameras) of %s_mesh + Style_%d fixtures; seeded He-normal VGG-19 weights "
                     "(pretrained weights need a download)" % (args.mesh, args.style),
-            "config": {"workload": "%s: %s_mesh + Style_%d, %dx%d, %d views/GPU/iter, %s (second_approach loop body)"
-                                   % (cfg_name, args.mesh, args.style, S, S, Bv, tgt),
+            "config": {"workload": "%s: %s_mesh + Style_%d, %dx%d, %d views/GPU/iter, %s, %s backgrounds (%s)"
+                                   % (cfg_name, args.mesh, args.style, S, S, Bv, tgt, bg, loop),
                        "global_views_per_step": global_views, "texture": "%dx%d" % (S, S),
-                       "targets_hoisted": not args.no_hoist,
+                       "targets_hoisted": hoisted,
                        "parallelism": "views sharded dp%d, RCCL all-reduce of the texture gradient" % world},
             "first_step_loss": first_step_loss, "final_loss": final_loss,
             "roofline": roofline,
@@ -489,7 +600,7 @@ def main():
             res["kernels"] = kernels
         if layers and args.layers:
             res["layers"] = layers
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.approach == "second":
             try:
                 res["cpu_baseline"] = cb = cpu_baseline(S, Bv, 0)
                 if std_cfg:
