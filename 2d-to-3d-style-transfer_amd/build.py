@@ -47,15 +47,18 @@ def _newer(src, dst, extra=()):
 
 def build(force=False, jobs=4, verbose=True):
     os.makedirs(OBJDIR, exist_ok=True)
-    hdrs = (os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "st3d.h"), os.path.abspath(__file__))
+    hdrs = (os.path.join(CSRC, "common.h"), os.path.join(CSRC, "det.h"), os.path.join(CSRC, "lab", "wino8.inc"),
+            os.path.join(HERE, "..", "include", "st3d.h"), os.path.abspath(__file__))
     todo = []
     objs = []
     for src, flags in SOURCES.items():
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJDIR, src.replace(".hip", ".o"))
         objs.append(o)
-        if os.environ.get("ST3D_WINO_DEBUG") and src == "wino.hip":
-            flags = flags + ["-DST3D_WINO_DEBUG"]      # s_memtime stamps for tools/wino_bench.py; never in the shipped library
+        if src == "wino.hip" and (os.environ.get("ST3D_LAB") or os.environ.get("ST3D_WINO_DEBUG")):
+            # lab build (never the shipped library): the retired 8-wave kernel (csrc/lab/wino8.inc, ST3D_WINO_VARIANT=8), the
+            # diagnostic instantiations of wino4_kernel (ST3D_WINO_DBGMODE) and the s_memtime stamps of tools/wino_bench.py
+            flags = flags + ["-DST3D_LAB", "-DST3D_WINO_DEBUG"]
         if src == "wino.hip":
             for k in ("ST3D_WINO_SCHED", "ST3D_WINO_KS", "ST3D_WINO_UDEPTH"):     # stage-loop schedule variants (A/B runs, tools/wino_sched_ab.sh)
                 if os.environ.get(k):

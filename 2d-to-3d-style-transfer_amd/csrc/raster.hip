@@ -361,7 +361,8 @@ static int raster_bin_cap(int F) {
 extern "C" size_t st3d_raster_workspace_bytes_binned(int B, int F, int S) {
     const int nb = st3d::cdiv(st3d::cdiv(S, TILE), BIN);
     size_t base = (st3d_raster_workspace_bytes(B, F) + 15) & ~(size_t)15;
-    return base + (size_t)B * nb * nb * ((size_t)raster_bin_cap(F) + 1) * sizeof(int);
+    // [counts: B*nb*nb ints, padded to an even number][lists: cap (even) ints per bin] -- the lists are read as int2
+    return base + ((((size_t)B * nb * nb + 1) & ~(size_t)1) + (size_t)B * nb * nb * raster_bin_cap(F)) * sizeof(int);
 }
 
 extern "C" int st3d_face_setup(const float *verts_ndc, const int32_t *faces, int B, int V, int F, void *face_records,
@@ -396,7 +397,7 @@ extern "C" int st3d_raster_fwd(const float *verts_ndc, const int32_t *faces, int
     if (allow_bins && Fp > 2048 && workspace_bytes >= st3d_raster_workspace_bytes_binned(B, F, S)) {
         const size_t base = (st3d_raster_workspace_bytes(B, F) + 15) & ~(size_t)15;
         int *bin_count = reinterpret_cast<int *>(reinterpret_cast<char *>(workspace) + base);
-        int *bin_list = bin_count + (size_t)B * nb * nb;
+        int *bin_list = bin_count + (((size_t)B * nb * nb + 1) & ~(size_t)1);      // 8-byte aligned: read as int2 (cap is even)
         raster_bin_kernel<<<dim3(nb * nb, B), 256, 0, s>>>(words, Fp, nb, cap, bin_count, bin_list);
         ST3D_LAUNCH_CHECK();
         raster_tile_kernel<<<dim3(tiles, tiles, B), 256, 0, s>>>(rec, words, F, Fp, S, pix_to_face, zbuf, bary, dists, bin_count,

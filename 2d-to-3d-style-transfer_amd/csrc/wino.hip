@@ -9,24 +9,15 @@
 //   M[xi] = U[xi]^T V[xi]        -- 16 independent GEMMs (M = cout, N = tile, K = cin) on
 //                                   v_mfma_f32_32x32x2_f32
 //
-// Mapping: one 512-thread workgroup = 64 cout x 64 tiles (8 rows x 32 columns of pixels).
-// 8 waves = 4 (row a of the 4x4 Winograd domain: xi = 4a..4a+3) x 2 (32-cout halves); every wave
-// covers all 64 tiles: 8 MFMA tiles = 128 accumulator VGPRs, two waves per SIMD (they hide each
-// other's LDS-operand latency and barrier bubbles).  The output transform A^T M A runs along b in
-// registers and along a through ONE [4][64][64] LDS exchange per output column; after it a lane
-// owns a whole 2x2 output tile, which IS the MaxPool2d(2,2) window, so pooling (+argmax) fuses
-// into the epilogue for free and the stores are one cout row (64 tiles) per wave instruction.
-// K loop: chunks of 4 input channels.  Each Winograd-domain filter element is consumed by exactly
-// one wave, so U never touches LDS: the pack stores every lane's 8 A operands of a chunk
-// contiguously and the wave fetches them one chunk ahead with two coalesced dwordx4 loads.
-// The haloed patch [4][10][34] is staged global->registers->LDS two chunks ahead
-// (triple-buffered), the input transform of chunk c+1 (patch -> V, one (tile, channel,
-// row-half) per thread, ds_read_b64 / ds_write_b32) runs beside the MFMAs of chunk c
-// (double-buffered V, n-tile pairs interleaved so one ds_read_b64 yields both B operands):
-// one barrier per chunk; the two waves of a SIMD run the chunk's phases in opposite order
-// (stagger).  The ReLU gate / 2x2 max-unpool of the backward pass are fused into the patch load
-// exactly as in conv.hip.  The cout-tile index is the fastest grid dimension so the workgroups
-// of one XCD (dispatch is round-robin over the 8 XCDs) stream the same U slice from that XCD's L2.
+// Mapping (wino4_kernel, the one Winograd kernel of the shipped library): one 256-thread workgroup = 64 cout x 32 tiles
+// (4 rows x 32 columns of pixels), two workgroups per CU.  Wave w accumulates row a = w of the 4x4 Winograd domain
+// (xi = 4a..4a+3) for both 32-cout halves: 8 MFMA tiles = 128 accumulator VGPRs.  A operands (U) never touch LDS -- the
+// pack stores every lane's operands of a 4-channel sub-chunk contiguously, fetched two sub-chunks ahead through a buffer
+// descriptor; B operands (V) are computed by each lane from the haloed patch, staged 8 channels per barrier through a
+// 3-deep LDS ring.  The output transform runs along b in registers and along a through one LDS exchange; after it a lane
+// owns 2x2 output tiles, which ARE the MaxPool2d(2,2) windows, so pooling (+argmax) fuses into the epilogue, as do the
+// ReLU gate / max-unpool of the backward pass (into the patch staging or, producer-side, into the output store).
+// Details at the kernel.  (The round-1 kernel -- 512 threads, 64 x 64 tiles -- lives in lab/wino8.inc, lab builds only.)
 #include <stdlib.h>
 
 #include <type_traits>
@@ -42,18 +33,9 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int KC = 4;                 // input channels per MFMA sub-chunk (2 k-steps of 2)
-constexpr int KS = 8;                 // input channels staged per barrier (2 sub-chunks)
 constexpr int BCO = 64;               // cout per workgroup
-constexpr int TROWS = 8, TCOLS = 32;  // output pixels per workgroup
-constexpr int NT = 512;               // threads per workgroup (8 waves, 2 per SIMD)
-constexpr int PR = TROWS + 2, PC = TCOLS + 2;    // haloed patch: 10 rows x 34 columns per channel
 constexpr int PCP = 48;                          // LDS row pitch: 2 rows apart = 96 words = 32 banks (mod 64),
                                                  // so the two tile rows of a half-wave never share a bank
-constexpr int PS = PR * PCP;                     // 480 floats per channel
-constexpr int P_STAGE = KS * PS + 8;             // 3848 floats = 15 KB per stage (+4 leading, +4 trailing floats of slack)
-constexpr int EX_FLOATS = 4 * 64 * 64;           // epilogue exchange [4 a][64 co][64 tiles]
-constexpr int LOOP_FLOATS = 3 * P_STAGE;
-constexpr int SMEM_FLOATS = EX_FLOATS > LOOP_FLOATS ? EX_FLOATS : LOOP_FLOATS;   // 64 KB
 
 struct WinoArgs {
     const float *x;       // MODE 0/1: (N,Cin,H,W); MODE 2: pooled-resolution gradient (N,Cin,H/2,W/2)
@@ -73,359 +55,9 @@ struct WinoArgs {
     float addc;           // addc * (activation - target) (losses.py:24-28) lands in the same store; nullptr = none
 };
 
-// Wave roles (8 waves): a = wave & 3 is the row of the 4x4 Winograd domain the wave accumulates
-// (xi = 4a .. 4a+3), mh = wave >> 2 the 32-cout half; every wave covers all 64 tiles (2 MFMA
-// n-tiles): 8 MFMA tiles = 128 accumulator VGPRs per wave, two waves per SIMD.
-//  * A operands (U): each element is consumed by exactly ONE wave, so U never touches LDS; the
-//    pack stores every lane's 8 operands of a sub-chunk contiguously (two coalesced dwordx4
-//    loads, issued one sub-chunk ahead).
-//  * B operands (V = B^T d B): a lane computes ITS OWN four operands (b = 0..3 of the wave's row
-//    a) for its (tile, channel) straight from the staged patch: 2 patch rows x 4 columns
-//    (ds_read_b64 x 4), one fma + one add/sub each.  V is never written to LDS, so the only
-//    cross-wave dependency is the patch itself, staged 8 channels per barrier two stages ahead
-//    (triple buffer), and a wave fetches the patch rows of the NEXT sub-chunk -- across the
-//    barrier too -- while the MFMAs of the current one run: no LDS latency behind a barrier.
-template <int MODE, int EPI, int DBG = 0>
-__global__ __launch_bounds__(NT, 2) void wino_kernel(const WinoArgs a) {
-    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
-    float *sP = smem;                          // [3][KS][PR][PCP]
-
-    unsigned long long t_entry = 0, t_loop0 = 0, t_loop1 = 0;      // DBG builds: whole-workgroup phase stamps
-    if (DBG) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_entry) :: "memory"); }
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, lhi = lane >> 5;
-    const int wa = wave & 3, mh = wave >> 2;
-
-    // grid: x = cout tile (fastest) + n_ct * (pixel tile + tiles * image)
-    int bid = blockIdx.x;
-    const int ct = bid % a.n_ct; bid /= a.n_ct;
-    const int tile_x = bid % a.tiles_x; bid /= a.tiles_x;
-    const int tile_y = bid % a.tiles_y;
-    const int n = bid / a.tiles_y;
-    const int x0 = tile_x * TCOLS, y0 = tile_y * TROWS, co0 = ct * BCO;
-    const int H = a.H, W = a.W;
-    const size_t HW = (size_t)H * W;
-    const int Hp = H >> 1, Wp = W >> 1;
-    const size_t in_plane = (MODE == 2) ? (size_t)Hp * Wp : HW;
-    const int nstages = a.Cin / KS;
-
-    // ---- staging.  One item = 4 consecutive columns of one patch row of one channel, fetched
-    // with ONE 16-byte load: 10 rows x 10 items (columns x0-4 .. x0+35, 16-B aligned) x 8
-    // channels = 800 items per stage, two per thread.  Vector-memory instructions are the scarce
-    // resource of this loop (~12 issue cycles each, shared by the CU's 8 waves), so the patch
-    // is loaded wide and written to LDS narrow (4 ds_write_b32: the patch origin x0-1 is odd).
-    // The global address is a constant per-item byte offset + a SCALAR per-stage offset through
-    // a buffer descriptor: no vector ALU work per load (f32 MFMAs do not co-issue with VALU, so
-    // every VALU instruction in this loop is paid in matrix-pipe time).  Items outside the image
-    // (W % 4 == 0: a whole item is inside or outside) use an offset beyond num_records and read
-    // 0 = the convolution's zero padding.
-    constexpr int ITEMS = KS * PR * 10, IPT = 2;
-    const unsigned kOob = 0x80000000u;
-    unsigned voff[IPT];        // byte offset inside the image (channel included)
-    int loff[IPT];             // LDS float offset of the item's first column (may be 3 floats before the row)
-    unsigned rowbit[MODE == 2 ? IPT : 1];
-#pragma unroll
-    for (int i = 0; i < IPT; ++i) {
-        const int e = tid + i * NT;
-        const int ci = e / 100, rem = e - ci * 100;
-        const int r = rem / 10, l = rem - r * 10;
-        const int gy = y0 + r - 1, gx0 = x0 - 4 + 4 * l;
-        const bool ok = e < ITEMS && gy >= 0 && gy < H && gx0 >= 0 && gx0 < W;
-        if (MODE == 2) {
-            voff[i] = ok ? (unsigned)((ci * in_plane + (size_t)(gy >> 1) * Wp + (gx0 >> 1)) * 4) : kOob;
-            rowbit[i] = (gy & 1) << 1;
-        } else {
-            voff[i] = ok ? (unsigned)((ci * in_plane + (size_t)gy * W + gx0) * 4) : kOob;
-        }
-        loff[i] = (e < ITEMS) ? (4 + ci * PS + r * PCP + 4 * l - 3) : -1;     // +4: room for the first row's columns -3..-1
-    }
-    const unsigned img_bytes = (unsigned)((size_t)a.Cin * in_plane * 4);
-    const unsigned stage_bytes = (unsigned)(KS * in_plane * 4);
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(a.x + (size_t)n * a.Cin * in_plane), 0, img_bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t raux = rx, ridx = rx;
-    if (MODE != 0)
-        raux = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.aux + (size_t)n * a.Cin * in_plane), 0, img_bytes, 0x00020000);
-    if (MODE == 2)
-        ridx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.idx + (size_t)n * a.Cin * in_plane), 0, img_bytes / 4, 0x00020000);
-    // this lane's A operands of sub-chunk s: 8 floats (32 B) at byte offset uvoff + s * 16384
-    const int nsub = a.Cin / KC;
-    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(a.U + (size_t)ct * nsub * 4096), 0, (unsigned)((size_t)nsub * 4096 * 4), 0x00020000);
-    const unsigned uvoff = (unsigned)((wave * 64 + lane) * 32);
-
-    // MODE 0/1: xv = 4 gradient/activation columns, xa = 4 gate columns (MODE 1)
-    // MODE 2  : xv[0..1] = 2 pooled-resolution gradients, xa[0..1] = 2 pooled values, xi = 2 argmax bytes
-    f32x4 xv[IPT];
-    f32x4 xa[MODE == 1 ? IPT : 1];
-    f32x2 xg[MODE == 2 ? IPT : 1], xp[MODE == 2 ? IPT : 1];
-    unsigned xi[MODE == 2 ? IPT : 1];
-
-    auto gload = [&](int st) __attribute__((always_inline)) {
-        const unsigned so = (unsigned)st * stage_bytes;
-#pragma unroll
-        for (int i = 0; i < IPT; ++i) {
-            if (MODE == 2) {
-                xg[i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rx, voff[i], so, 0));
-                xp[i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(raux, voff[i], so, 0));
-                xi[i] = __builtin_amdgcn_raw_buffer_load_b16(ridx, voff[i] == kOob ? kOob : voff[i] / 4, so / 4, 0);
-            } else {
-                xv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff[i], so, 0));
-                if (MODE == 1) xa[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(raux, voff[i], so, 0));
-            }
-        }
-    };
-    auto lstore = [&](int buf) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < IPT; ++i) {
-            if (loff[i] >= 0) {
-                float *dst = &sP[buf * P_STAGE + loff[i]];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float v;
-                    if (MODE == 0) v = xv[i][j];
-                    if (MODE == 1) v = (xa[i][j] > 0.f) ? xv[i][j] : 0.f;
-                    if (MODE == 2) {
-                        const unsigned ib = (xi[i] >> (8 * (j >> 1))) & 0xffu;
-                        v = (xp[i][j >> 1] > 0.f && ib == (rowbit[i] | (j & 1))) ? xg[i][j >> 1] : 0.f;
-                    }
-                    dst[j] = v;
-                }
-            }
-        }
-    };
-
-    // B operands.  Row transform of the wave's row a: t = d[r1] + sg * d[r2]
-    //   a = 0: d0 - d2 ; a = 1: d1 + d2 ; a = 2: d2 - d1 ; a = 3: d1 - d3
-    const int r1 = (wa == 0) ? 0 : (wa == 2 ? 2 : 1);
-    const int r2 = (wa == 3) ? 3 : (wa == 2 ? 1 : 2);
-    const float sg = (wa == 1) ? 1.f : -1.f;
-    // lane -> (tile row within the n-tile, tile column, channel parity)
-    const int lane_off = lhi * PS + (2 * (l31 >> 4)) * PCP + 2 * (l31 & 15);
-    const int off1 = lane_off + r1 * PCP, off2 = lane_off + r2 * PCP;
-    // raw patch rows of one sub-chunk: [ks][nn][row 1/2][4 columns]
-    struct Raw { f32x2 v[2][2][2][2]; };
-    auto pread = [&](int buf, int sub, Raw &d) __attribute__((always_inline)) {
-        const float *p = &sP[buf * P_STAGE + 4 + sub * KC * PS];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int nn = 0; nn < 2; ++nn) {
-                const float *q1 = p + off1 + (2 * ks) * PS + (4 * nn) * PCP;
-                const float *q2 = p + off2 + (2 * ks) * PS + (4 * nn) * PCP;
-                d.v[ks][nn][0][0] = *reinterpret_cast<const f32x2 *>(q1);
-                d.v[ks][nn][0][1] = *reinterpret_cast<const f32x2 *>(q1 + 2);
-                d.v[ks][nn][1][0] = *reinterpret_cast<const f32x2 *>(q2);
-                d.v[ks][nn][1][1] = *reinterpret_cast<const f32x2 *>(q2 + 2);
-            }
-    };
-    struct Bop { float v[2][2][4]; };      // [ks][nn][q = b]
-    auto bcompute = [&](const Raw &d, Bop &bv) __attribute__((always_inline)) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int nn = 0; nn < 2; ++nn) {
-                const float t0 = d.v[ks][nn][0][0][0] + sg * d.v[ks][nn][1][0][0];
-                const float t1 = d.v[ks][nn][0][0][1] + sg * d.v[ks][nn][1][0][1];
-                const float t2 = d.v[ks][nn][0][1][0] + sg * d.v[ks][nn][1][1][0];
-                const float t3 = d.v[ks][nn][0][1][1] + sg * d.v[ks][nn][1][1][1];
-                bv.v[ks][nn][0] = t0 - t2;
-                bv.v[ks][nn][1] = t1 + t2;
-                bv.v[ks][nn][2] = t2 - t1;
-                bv.v[ks][nn][3] = t1 - t3;
-            }
-    };
-
-    f32x16 acc[4][2];      // [b][n]
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int nn = 0; nn < 2; ++nn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[q][nn][r] = 0.f;
-
-    // Waves w and w+4 share a SIMD.  Running the same program they would reach their MFMA bursts,
-    // their staging work and the barrier together and the matrix pipe would idle through every
-    // non-MFMA phase, so the halves are STAGGERED: waves 0-3 ("A") stage (global loads at the top,
-    // LDS stores at the bottom) around their MFMAs, waves 4-7 ("B") store at the top what they
-    // loaded during the previous stage.  Both do the same work between two barriers.
-    const bool isA = __builtin_amdgcn_readfirstlane(wave) < 4;
-    unsigned long long tp[6] = {0, 0, 0, 0, 0, 0};
-#define PSTAMP(k) if (DBG) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tp[k]) :: "memory"); }
-    PSTAMP(0)
-    gload(0);
-    lstore(0);
-    PSTAMP(1)
-    gload(nstages > 1 ? 1 : 0);
-    lstore(1);
-    PSTAMP(2)
-    if (!isA) gload(min(2, nstages - 1));      // B holds stage c+2 in registers across the barrier
-    auto uload = [&](int sub, f32x4 &u0, f32x4 &u1) __attribute__((always_inline)) {
-        const unsigned so = (unsigned)min(sub, nsub - 1) * 16384u;
-        u0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, uvoff, so, 0));
-        u1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, uvoff + 16, so, 0));
-    };
-    f32x4 ua0, ua1;
-    uload(0, ua0, ua1);
-    PSTAMP(3)
-    __syncthreads();
-    PSTAMP(4)
-    Raw draw;
-    Bop bcur, bnext;
-    pread(0, 0, draw);
-    bcompute(draw, bcur);
-    PSTAMP(5)
-
-#define WINO_MFMA(ua, bv, ks, q)                                                                      \
-        acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[q], bv.v[ks][0][q], acc[q][0], 0, 0, 0);   \
-        acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[q], bv.v[ks][1][q], acc[q][1], 0, 0, 0);
-#define WINO_ULOAD(s_, u0, u1) f32x4 u0, u1; uload((s_), u0, u1);
-    // One stage = 8 input channels = sub-chunks s0 (operands in bcur/ua) and s1.  ONE basic block
-    // per stage with the order pinned (in-order issue: what should overlap a wave's own MFMAs
-    // must sit between them in program order).  Tail stages redo clamped, harmless work.
-    int pb = 0;            // patch buffer of stage c (mod 3)
-    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
-    if (DBG) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast) :: "memory"); t_loop0 = tlast; }
-#define STAMP(k) if (DBG) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); tsum[k] += t_ - tlast; tlast = t_; }
-    // Per stage each wave alternates four 8-MFMA bursts (M) with four overhead slots (O); a wave
-    // issues in order, so while it sits in a burst nothing else of it issues, and while it is in
-    // an overhead slot the matrix pipe is free for its partner.  A starts with a burst (its
-    // operands were prepared before the barrier), B with an overhead slot:
-    //   A:  M1 | O  | M2 | O  | M3 | O  | M4 | O  | barrier
-    //   B:  O  | M1 | O  | M2 | O  | M3 | O  | M4 | barrier
-    if (isA) {
-        for (int c = 0; c < nstages; ++c) {
-            const int pb1 = (pb == 2) ? 0 : pb + 1, pb2 = (pb1 == 2) ? 0 : pb1 + 1;
-            STAMP(0)
-            WINO_MFMA(ua0, bcur, 0, 0) WINO_MFMA(ua0, bcur, 0, 1) WINO_MFMA(ua0, bcur, 0, 2) WINO_MFMA(ua0, bcur, 0, 3)
-            __builtin_amdgcn_sched_barrier(0);
-            STAMP(1)
-            gload(min(c + 2, nstages - 1));
-            WINO_ULOAD(2 * c + 1, ub0, ub1)
-            pread(pb, 1, draw);
-            __builtin_amdgcn_sched_barrier(0);
-            STAMP(2)
-            WINO_MFMA(ua1, bcur, 1, 0) WINO_MFMA(ua1, bcur, 1, 1) WINO_MFMA(ua1, bcur, 1, 2) WINO_MFMA(ua1, bcur, 1, 3)
-            __builtin_amdgcn_sched_barrier(0);
-            STAMP(3)
-            bcompute(draw, bnext);
-            __builtin_amdgcn_sched_barrier(0);
-            WINO_MFMA(ub0, bnext, 0, 0) WINO_MFMA(ub0, bnext, 0, 1) WINO_MFMA(ub0, bnext, 0, 2) WINO_MFMA(ub0, bnext, 0, 3)
-            __builtin_amdgcn_sched_barrier(0);
-            STAMP(4)
-            uload(2 * c + 2, ua0, ua1);
-            pread(pb1, 0, draw);           // first sub-chunk of the NEXT stage (staged one barrier ago)
-            __builtin_amdgcn_sched_barrier(0);
-            WINO_MFMA(ub1, bnext, 1, 0) WINO_MFMA(ub1, bnext, 1, 1) WINO_MFMA(ub1, bnext, 1, 2) WINO_MFMA(ub1, bnext, 1, 3)
-            __builtin_amdgcn_sched_barrier(0);
-            STAMP(5)
-            bcompute(draw, bcur);
-            lstore(pb2);
-            STAMP(6)
-            __syncthreads();
-            STAMP(7)
-            pb = pb1;
-        }
-    } else {
-        for (int c = 0; c < nstages; ++c) {
-            const int pb1 = (pb == 2) ? 0 : pb + 1, pb2 = (pb1 == 2) ? 0 : pb1 + 1;
-            lstore(pb2);                                    // stage c+2, loaded during stage c-1
-            gload(min(c + 3, nstages - 1));
-            WINO_ULOAD(2 * c + 1, ub0, ub1)
-            pread(pb, 1, draw);
-            __builtin_amdgcn_sched_barrier(0);
-            WINO_MFMA(ua0, bcur, 0, 0) WINO_MFMA(ua0, bcur, 0, 1) WINO_MFMA(ua0, bcur, 0, 2) WINO_MFMA(ua0, bcur, 0, 3)
-            __builtin_amdgcn_sched_barrier(0);
-            bcompute(draw, bnext);
-            __builtin_amdgcn_sched_barrier(0);
-            WINO_MFMA(ua1, bcur, 1, 0) WINO_MFMA(ua1, bcur, 1, 1) WINO_MFMA(ua1, bcur, 1, 2) WINO_MFMA(ua1, bcur, 1, 3)
-            __builtin_amdgcn_sched_barrier(0);
-            uload(2 * c + 2, ua0, ua1);
-            pread(pb1, 0, draw);
-            __builtin_amdgcn_sched_barrier(0);
-            WINO_MFMA(ub0, bnext, 0, 0) WINO_MFMA(ub0, bnext, 0, 1) WINO_MFMA(ub0, bnext, 0, 2) WINO_MFMA(ub0, bnext, 0, 3)
-            __builtin_amdgcn_sched_barrier(0);
-            bcompute(draw, bcur);
-            __builtin_amdgcn_sched_barrier(0);
-            WINO_MFMA(ub1, bnext, 1, 0) WINO_MFMA(ub1, bnext, 1, 1) WINO_MFMA(ub1, bnext, 1, 2) WINO_MFMA(ub1, bnext, 1, 3)
-            __syncthreads();
-            pb = pb1;
-        }
-    }
-#undef WINO_MFMA
-#undef WINO_ULOAD
-    if (DBG) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_loop1) :: "memory"); }
-    if (DBG && a.dbg && blockIdx.x == 300 && lane == 0) { for (int k = 0; k < 8; ++k) a.dbg[wave * 8 + k] = tsum[k]; }
-
-    // ---- epilogue: Y = A^T M A.  Along b in registers (z_j), along a through LDS.
-    //   z_0 = m_a0 + m_a1 + m_a2 ; z_1 = m_a1 - m_a2 - m_a3      (this wave's row a)
-    //   y_0j = z_j(a=0) + z_j(a=1) + z_j(a=2) ; y_1j = z_j(a=1) - z_j(a=2) - z_j(a=3)
-    float *ex = smem;      // [4 a][64 co][64 tiles]; the last main-loop barrier has been passed
-    float yv[8][2][2];     // per thread: 8 (co, tile) elements x 2x2 outputs
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        if (j == 1) __syncthreads();           // pass-0 reads done before the buffer is rewritten
-#pragma unroll
-        for (int nn = 0; nn < 2; ++nn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float z = j == 0 ? (acc[0][nn][r] + acc[1][nn][r] + acc[2][nn][r])
-                                       : (acc[1][nn][r] - acc[2][nn][r] - acc[3][nn][r]);
-                const int co = mh * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                ex[(wa * 64 + co) * 64 + nn * 32 + l31] = z;
-            }
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int co = e * 8 + wave;
-            const float z0 = ex[(0 * 64 + co) * 64 + lane], z1 = ex[(1 * 64 + co) * 64 + lane];
-            const float z2 = ex[(2 * 64 + co) * 64 + lane], z3 = ex[(3 * 64 + co) * 64 + lane];
-            yv[e][0][j] = z0 + z1 + z2;
-            yv[e][1][j] = z1 - z2 - z3;
-        }
-    }
-    const int oy = y0 + 2 * (lane >> 4), ox = x0 + 2 * (lane & 15);
-    const bool inb = oy < H && ox < W;     // H, W even: the whole 2x2 tile is inside or outside
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int co = co0 + e * 8 + wave;
-        const float bsum = a.bias ? a.bias[co] : 0.f;
-        float y00 = yv[e][0][0] + bsum, y01 = yv[e][0][1] + bsum, y10 = yv[e][1][0] + bsum, y11 = yv[e][1][1] + bsum;
-        if (a.relu) {
-            y00 = y00 > 0.f ? y00 : 0.f; y01 = y01 > 0.f ? y01 : 0.f;
-            y10 = y10 > 0.f ? y10 : 0.f; y11 = y11 > 0.f ? y11 : 0.f;
-        }
-        if (!inb) continue;
-        if (a.y) {
-            float *dst = a.y + ((size_t)n * a.Cout + co) * HW + (size_t)oy * W + ox;
-            f32x2 r0, r1;
-            r0[0] = y00; r0[1] = y01; r1[0] = y10; r1[1] = y11;
-            *reinterpret_cast<f32x2 *>(dst) = r0;
-            *reinterpret_cast<f32x2 *>(dst + W) = r1;
-        }
-        if (EPI == 1) {     // MaxPool2d(2,2): first maximum in row-major window order (ATen)
-            float best = y00; int bi = 0;
-            if (y01 > best || y01 != y01) { best = y01; bi = 1; }
-            if (y10 > best || y10 != y10) { best = y10; bi = 2; }
-            if (y11 > best || y11 != y11) { best = y11; bi = 3; }
-            const size_t po = ((size_t)n * a.Cout + co) * (size_t)Hp * Wp + (size_t)(oy >> 1) * Wp + (ox >> 1);
-            a.yp[po] = best;
-            if (a.yidx) a.yidx[po] = (uint8_t)bi;
-        }
-    }
-    if (DBG && a.dbg && blockIdx.x == 300 && lane == 0) {       // prologue / loop / epilogue cycles of this wave
-        unsigned long long t_end;
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_end) :: "memory");
-        a.dbg[64 + wave * 4 + 0] = t_loop0 - t_entry; a.dbg[64 + wave * 4 + 1] = t_loop1 - t_loop0;
-        a.dbg[64 + wave * 4 + 2] = t_end - t_loop1; a.dbg[64 + wave * 4 + 3] = t_end - t_entry;
-        if (wave == 0 || wave == 4) {       // prologue split: setup | gload0+lstore0 | gload1+lstore1 | uload | barrier | pread+bcompute
-            unsigned long long *o = a.dbg + 96 + (wave >> 2) * 8;
-            o[0] = tp[0] - t_entry; o[1] = tp[1] - tp[0]; o[2] = tp[2] - tp[1]; o[3] = tp[3] - tp[2]; o[4] = tp[4] - tp[3];
-            o[5] = tp[5] - tp[4];
-        }
-    }
-}
+#ifdef ST3D_LAB
+#include "lab/wino8.inc"      // the retired 8-wave kernel: lab builds only (A/B runs, phase stamps)
+#endif
 
 // ------------------------------------------------------------------------------------------------------------------
 // wino4_kernel: the same algorithm on a HALF-SIZE workgroup -- 256 threads = 4 waves, 64 cout x 32 tiles (4 x 32
@@ -927,13 +559,14 @@ __global__ void wino_pack_kernel(const float *__restrict__ w, int Cout, int Cin,
     }
 }
 
-// ST3D_WINO_VARIANT=8 / 4 forces one kernel (A/B runs, tools/wino_layers.py).  Default: the half-size workgroups for every
-// layer -- measured faster on all twelve VGG shapes in both directions (4-8 % per layer).
+#ifdef ST3D_LAB
+// lab builds: ST3D_WINO_VARIANT=8 selects the retired 8-wave kernel (A/B runs, tools/wino_layers.py)
 int wino_variant(const WinoArgs &a) {
     static const int forced = [] { const char *e = getenv("ST3D_WINO_VARIANT"); return e ? atoi(e) : 0; }();
     if (forced == 4 || forced == 8) return forced;
     return 4;
 }
+#endif
 
 template <int MODE>
 int launch_wino4(WinoArgs a, hipStream_t s) {
@@ -977,6 +610,9 @@ int launch_wino4(WinoArgs a, hipStream_t s) {
 
 template <int MODE>
 int launch_wino(WinoArgs a, hipStream_t s) {
+#ifndef ST3D_LAB
+    return launch_wino4<MODE>(a, s);
+#else
     if ((wino_variant(a) == 4 && !a.dbg) || a.gate) return launch_wino4<MODE>(a, s);      // the output gate exists in wino4 only
     a.tiles_x = st3d::cdiv(a.W, TCOLS);
     a.tiles_y = st3d::cdiv(a.H, TROWS);
@@ -990,6 +626,7 @@ int launch_wino(WinoArgs a, hipStream_t s) {
     else wino_kernel<MODE, 0><<<(unsigned)blocks, NT, 0, s>>>(a);
     ST3D_LAUNCH_CHECK();
     return ST3D_OK;
+#endif
 }
 
 // The patch loads address one image through a buffer descriptor with 32-bit BYTE offsets (voff, stage_bytes) and

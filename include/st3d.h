@@ -16,6 +16,24 @@
  *   - kernels are asynchronous on the given stream (a hipStream_t passed as void*; NULL =
  *     the default stream).  Handles are not thread-safe (the reference is single-threaded).
  *   - tensors are fp32, contiguous; images are NCHW exactly as utils.py:70-76 builds them.
+ *
+ * Run-time switches the shipped library reads from the environment.  The defaults are the
+ * measured-best paths; every other value exists for same-box A/B runs and gives the same
+ * results (to fp32 summation order where a split count changes).
+ *   ST3D_CONV=direct            direct implicit-GEMM convolutions (conv.hip) instead of Winograd
+ *   ST3D_WINO_MAP=rr|xcd        block -> tile mapping of the Winograd launches
+ *   ST3D_PREGATE=0              every input-gradient applies its own ReLU gate (consumer side)
+ *   ST3D_TAP0_FUSED=0, ST3D_TAP0_J=1   separate relu1_1 Gram backward + conv1_1 input gradient / 4-byte accesses
+ *   ST3D_GRAM_MULTI=0           the five Gram forwards as separate launches (st3d_gram_fwd_multi)
+ *   ST3D_GRAM_MULTI_SCALE=n, ST3D_GRAM_MULTI_SCALES=a,b,c,d, ST3D_GRAM_MULTI_DEAL=1   split-K width / block order of the fused launch
+ *   ST3D_GRAM_FAST=0, ST3D_GRAM_DIAG_TRI=0, ST3D_GRAM_TARGET_WGS, ST3D_GRAM_NSPLIT   Gram forward: generic / full-tile kernels, split counts
+ *   ST3D_GRAM_BWD_MT, ST3D_GRAM_BWD_K64, ST3D_GRAM_BWD_SYM=0   Gram backward tile shapes / the general kernel
+ *   ST3D_RASTER_BINS=0          flat face sweep instead of the coarse 64x64-pixel bins
+ *   ST3D_POISON_PLAN=1          plan workspaces start as 0xFF (read-before-write detector of the tests)
+ * Read by the Python host (st3d/): ST3D_DETERMINISTIC=0 (float-atomic scatters), ST3D_GRAPH=1 (HIP-graph replay of
+ * the loss step), ST3D_NEAR_PLANE=raise, ST3D_MAX_PLANS, ST3D_VGG19_WEIGHTS, ST3D_DIST_BACKEND, ST3D_NCCL.
+ * Lab builds only (ST3D_LAB=1 python build.py; never shipped): ST3D_WINO_VARIANT=8 (the retired 8-wave Winograd
+ * kernel, csrc/lab/wino8.inc), ST3D_WINO_DBGMODE / ST3D_WINO_STAMP (diagnostic instantiations, s_memtime stamps).
  */
 #ifndef ST3D_H
 #define ST3D_H

@@ -108,7 +108,7 @@ CONV_CASES = [(2, 3, 64, 64, 64), (1, 64, 64, 48, 40), (2, 64, 128, 32, 32), (1,
               (1, 256, 256, 32, 32), (2, 512, 512, 16, 16), (1, 512, 512, 4, 4), (1, 3, 64, 33, 70)]
 
 
-@pytest.mark.parametrize("S,B", [(96, 2), (64, 1), (160, 3)])
+@pytest.mark.parametrize("S,B", [(96, 2), (64, 1), (160, 3), (160, 1)])      # 160: 3 x 3 bins per view -- odd counts (list alignment)
 def test_raster_does_not_depend_on_stale_workspace_contents(dev, ops, cow, S, B):
     """The rasteriser's workspace (face records, packed tile ranges, coarse bin lists) is a fresh torch.empty per call: it
     must read nothing it has not written.  The caching allocator is primed with blocks full of 0xFF.. / small positive
