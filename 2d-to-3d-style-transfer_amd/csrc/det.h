@@ -73,4 +73,15 @@ __device__ __forceinline__ float det_block_sum(float v, float *s4) {      // 256
     return (s4[0] + s4[1]) + (s4[2] + s4[3]);
 }
 
+// partials[block] = sum |x| over the block's grid-stride share (the bound of the texture scatters: every contribution is
+// a gradient value times blend and bilinear weights <= 1)
+static __global__ __launch_bounds__(256) void det_abs_sum_kernel(const float *__restrict__ x, size_t n, float *__restrict__ partials) {
+    __shared__ float s4[4];
+    float acc = 0.f;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) acc += fabsf(x[i]);
+    const float t = det_block_sum(acc, s4);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
 }  // namespace st3d_det

@@ -247,15 +247,7 @@ extern "C" int st3d_shade_bwd(const float *grad_rgb, const int32_t *pix_to_face,
 }
 
 namespace {
-// bound on any texel-channel sum: sum over the batch of |grad_rgb| (blend weight and bilinear weights are <= 1)
-__global__ __launch_bounds__(256) void abs_sum_kernel(const float *__restrict__ x, size_t n, float *__restrict__ partials) {
-    __shared__ float s4[4];
-    float acc = 0.f;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) acc += fabsf(x[i]);
-    const float t = st3d_det::det_block_sum(acc, s4);
-    if (threadIdx.x == 0) partials[blockIdx.x] = t;
-}
+// (bound on any texel-channel sum: sum over the batch of |grad_rgb| -- blend weight and bilinear weights are <= 1: st3d_det::det_abs_sum_kernel)
 constexpr int kDetPartials = 1024;
 }  // namespace
 
@@ -278,7 +270,7 @@ extern "C" int st3d_shade_bwd_det(const float *grad_rgb, const int32_t *pix_to_f
     float *partials = st3d_det::partials_of(workspace);
     long long *acc = st3d_det::accum_of(workspace, kDetPartials);
     const size_t npx = (size_t)B * 3 * S * S, nacc = (size_t)T * T * 3;
-    abs_sum_kernel<<<kDetPartials, 256, 0, s>>>(grad_rgb, npx, partials);
+    st3d_det::det_abs_sum_kernel<<<kDetPartials, 256, 0, s>>>(grad_rgb, npx, partials);
     ST3D_LAUNCH_CHECK();
     st3d_det::det_scale_kernel<<<1, 256, 0, s>>>(partials, kDetPartials, hdr);
     ST3D_LAUNCH_CHECK();

@@ -10,7 +10,10 @@
 // nearest candidates in registers (insertion into a depth-sorted list, K is a template parameter
 // so the list never leaves the VGPRs).  HBM-bound: S*S*K*24 B of fragments per view.
 // Built with -ffp-contract=off: same operation order as oracle/raster_ref.c:ref_rasterize_k.
+#include <type_traits>
+
 #include "common.h"
+#include "det.h"
 
 namespace {
 
@@ -309,16 +312,67 @@ struct SoftArgs {
     int B, S, T, K; float sigma, gamma, bg0, bg1, bg2;
 };
 
-// one thread per pixel, loop over the K layers twice (z_max first).  MODE 0: forward (rgb, alpha);
-// MODE 1: backward (texture atomics + per-layer d/d bary, d/d zbuf, d/d dists)
-template <int MODE>
+// one thread per pixel, loop over the K layers twice (z_max first).  MODE 0: forward (rgb, alpha), threads along rows;
+// MODE 1: backward (texture scatter + per-layer d/d bary, d/d zbuf, d/d dists), one workgroup per 16x16-pixel tile:
+// neighbouring pixels (and layers) share texels, so the contributions are first summed per texel in an LDS table (open
+// addressing on the texel index) and each distinct texel of the tile then costs three global atomics -- what
+// shade_bwd_kernel does for the specialised K = 1 path.  Round 2 issued one global float atomic per contribution: with a
+// mesh that fills the screen (config 5 after the vertices reach the camera) that was 12 ms per step.  DET 1: the same in
+// 64-bit fixed point (det.h; gtex is then the int64 accumulator array): bitwise reproducible.  A contribution that finds
+// no slot within kSoftProbe steps (K layers can touch more texels than the table holds) goes to global memory directly.
+constexpr int kSoftTexSlots = 2048, kSoftProbe = 24;
+
+template <int MODE, int DET = 0>
 __global__ __launch_bounds__(256) void soft_shade_kernel(const SoftArgs a, float *__restrict__ rgb, float *__restrict__ alpha_out,
                                                          const float *__restrict__ grad_rgb, float *__restrict__ gtex,
-                                                         float *__restrict__ gbary, float *__restrict__ gz, float *__restrict__ gd) {
+                                                         float *__restrict__ gbary, float *__restrict__ gz, float *__restrict__ gd,
+                                                         int tiles_x, const st3d_det::DetHeader *__restrict__ det) {
+    typedef typename std::conditional<DET != 0, unsigned long long, float>::type acc_t;
+    __shared__ int s_key[MODE == 1 ? kSoftTexSlots : 1];
+    __shared__ acc_t s_acc[MODE == 1 ? kSoftTexSlots : 1][3];
     const size_t HW = (size_t)a.S * a.S;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)a.B * HW) return;
-    const size_t b = i / HW, p = i - b * HW;
+    size_t i, b, p;
+    bool live;
+    const bool binned = MODE == 1 && gtex != nullptr;
+    if (MODE == 1) {
+        const int tid = threadIdx.x;
+        if (binned) {
+            for (int e = tid; e < kSoftTexSlots; e += 256) s_key[e] = -1;
+            for (int e = tid; e < kSoftTexSlots * 3; e += 256) (&s_acc[0][0])[e] = (acc_t)0;
+            __syncthreads();
+        }
+        const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+        const int yi = ty * 16 + (tid >> 4), xi = tx * 16 + (tid & 15);
+        live = yi < a.S && xi < a.S;
+        b = blockIdx.y; p = (size_t)yi * a.S + xi; i = b * HW + p;
+    } else {
+        i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (i >= (size_t)a.B * HW) return;
+        b = i / HW; p = i - b * HW; live = true;
+    }
+    const double dscale = (MODE == 1 && DET) ? det->scale : 1.0;
+    // texel (T x T index) += v[0..2] * w
+    auto deposit = [&](int texel, const float *v, float w) __attribute__((always_inline)) {
+        int slot = (int)(((unsigned)texel * 2654435761u) >> 21) & (kSoftTexSlots - 1);
+        bool found = false;
+        for (int tries = 0; tries < kSoftProbe; ++tries) {
+            const int prev = atomicCAS(&s_key[slot], -1, texel);
+            if (prev == -1 || prev == texel) { found = true; break; }
+            slot = (slot + 1) & (kSoftTexSlots - 1);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (DET) {
+                const unsigned long long q = (unsigned long long)st3d_det::det_quantise(v[c] * w, dscale);
+                if (found) atomicAdd(reinterpret_cast<unsigned long long *>(&s_acc[slot][c]), q);
+                else atomicAdd(reinterpret_cast<unsigned long long *>(gtex) + (size_t)texel * 3 + c, q);
+            } else {
+                if (found) atomicAdd(reinterpret_cast<float *>(&s_acc[slot][c]), v[c] * w);
+                else atomicAdd(gtex + (size_t)texel * 3 + c, v[c] * w);
+            }
+        }
+    };
+    if (live) {
     const int K = a.K, T = a.T;
     const float zr = 1.0f / (kZfar - kZnear);
     // pass 1: z_max (argmax = first maximum, as torch.max) and alpha
@@ -407,14 +461,21 @@ __global__ __launch_bounds__(256) void soft_shade_kernel(const SoftArgs a, float
         const float gc[3] = {g0, g1, g2};
         const float rr[3] = {r0, r1, r2};
         float gix = 0.f, giy = 0.f, dw = 0.f;
+        if (binned) {
+            const float gk3[3] = {g0 * kw, g1 * kw, g2 * kw};
+            if (q.vy0 && q.vx0) deposit((int)(o00 / 3), gk3, w00);
+            if (q.vy0 && q.vx1) deposit((int)(o01 / 3), gk3, w01);
+            if (q.vy1 && q.vx0) deposit((int)(o10 / 3), gk3, w10);
+            if (q.vy1 && q.vx1) deposit((int)(o11 / 3), gk3, w11);
+        }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float t00 = 0.f, t01 = 0.f, t10 = 0.f, t11 = 0.f;
             const float gck = gc[c] * kw;
-            if (q.vy0 && q.vx0) { t00 = a.tex[o00 + c]; if (gtex) atomicAdd(gtex + o00 + c, gck * w00); }
-            if (q.vy0 && q.vx1) { t01 = a.tex[o01 + c]; if (gtex) atomicAdd(gtex + o01 + c, gck * w01); }
-            if (q.vy1 && q.vx0) { t10 = a.tex[o10 + c]; if (gtex) atomicAdd(gtex + o10 + c, gck * w10); }
-            if (q.vy1 && q.vx1) { t11 = a.tex[o11 + c]; if (gtex) atomicAdd(gtex + o11 + c, gck * w11); }
+            if (q.vy0 && q.vx0) t00 = a.tex[o00 + c];
+            if (q.vy0 && q.vx1) t01 = a.tex[o01 + c];
+            if (q.vy1 && q.vx0) t10 = a.tex[o10 + c];
+            if (q.vy1 && q.vx1) t11 = a.tex[o11 + c];
             const float tc = t00 * w00 + t01 * w01 + t10 * w10 + t11 * w11;
             dw += gc[c] * (tc - rr[c]) / denom;
             gix += gck * ((t01 - t00) * q.wy0 + (t11 - t10) * q.wy1);
@@ -436,26 +497,31 @@ __global__ __launch_bounds__(256) void soft_shade_kernel(const SoftArgs a, float
     }
     // z_max = max_k z_inv_k (clamped): its gradient goes to the arg-max layer
     if (gz && kmax >= 0 && !zclamped) gz[i * K + kmax] += -dzmax * zr;
+    }   // live
+    if (binned) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < kSoftTexSlots * 3; e += 256) {
+            const int slot = e / 3, c = e - slot * 3;
+            const int texel = s_key[slot];
+            if (texel < 0) continue;
+            const acc_t v = s_acc[slot][c];
+            if (v == (acc_t)0) continue;
+            if (DET) atomicAdd(reinterpret_cast<unsigned long long *>(gtex) + (size_t)texel * 3 + c, (unsigned long long)v);
+            else atomicAdd(gtex + (size_t)texel * 3 + c, (float)v);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------ raster backward
 // d loss / d (clipped barycentrics, depth, signed distance) per (pixel, layer) -> projected vertices
-__global__ __launch_bounds__(256) void raster_k_bwd_kernel(const float *__restrict__ gbary, const float *__restrict__ gzb,
-                                                           const float *__restrict__ gdist, const int32_t *__restrict__ p2f,
-                                                           const float *__restrict__ ndc, const int32_t *__restrict__ faces,
-                                                           int B, int V, int S, int K, int clip, int persp,
-                                                           float *__restrict__ gndc, const int32_t *__restrict__ frag_slot,
-                                                           float z_clip) {
-    const size_t HW = (size_t)S * S;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)B * HW * K) return;
-    const int f = p2f[i];
-    if (f < 0) return;
-    const size_t pix = i / K;
-    const size_t b = pix / HW, p = pix - b * HW;
-    const int yi = (int)(p / S), xi = (int)(p - (size_t)yi * S);
+// the nine contributions of fragment i (= (pixel, layer)) of face f to the face's three projected vertices, in the face's
+// own vertex order: c9 = {d/dx0, d/dy0, d/dz0, d/dx1, ...}
+__device__ __forceinline__ void raster_k_frag_grad(const float *__restrict__ gbary, const float *__restrict__ gzb,
+                                                   const float *__restrict__ gdist, const float *__restrict__ vb,
+                                                   const int32_t *__restrict__ faces, int S, int clip, int persp,
+                                                   const int32_t *__restrict__ frag_slot, float z_clip, size_t i, int f, int xi,
+                                                   int yi, float c9[9]) {
     const float px = pix_to_ndc(S - 1 - xi, S), py = pix_to_ndc(S - 1 - yi, S);
-    const float *vb = ndc + b * (size_t)V * 3;
     const int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
     float x0 = vb[3 * i0], y0 = vb[3 * i0 + 1], z0 = vb[3 * i0 + 2];
     float x1 = vb[3 * i1], y1 = vb[3 * i1 + 1], z1 = vb[3 * i1 + 2];
@@ -557,7 +623,6 @@ __global__ __launch_bounds__(256) void raster_k_bwd_kernel(const float *__restri
         else if (e == 1) { gx1 += gax; gy1 += gay; gx2 += gbx; gy2 += gby; }
         else { gx2 += gax; gy2 += gay; gx0 += gbx; gy0 += gby; }
     }
-    float *gb = gndc + b * (size_t)V * 3;
     if (ccode > 1) {
         // sub-triangle vertices q0 q1 q2 -> the face's p1 p2 p3 (indices k1 k2 k3 in the face) through p4 = cut(p1, p2, w2),
         // p5 = cut(p1, p3, w3), w2 = (z1 - zc) / (z1 - z2), w3 likewise; M's dependence on w2 / w3 included
@@ -602,18 +667,104 @@ __global__ __launch_bounds__(256) void raster_k_bwd_kernel(const float *__restri
         gp[0][2] += dw2 * (z_clip - P[1][2]) / (d12 * d12) + dw3 * (z_clip - P[2][2]) / (d13 * d13);
         gp[1][2] += dw2 * (P[0][2] - z_clip) / (d12 * d12);
         gp[2][2] += dw3 * (P[0][2] - z_clip) / (d13 * d13);
-        const int vi[3] = {i0, i1, i2};
         const int ks[3] = {k1, k2, k3};
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const int vtx = vi[ks[r]];
-            atomicAdd(gb + 3 * vtx, gp[r][0]); atomicAdd(gb + 3 * vtx + 1, gp[r][1]); atomicAdd(gb + 3 * vtx + 2, gp[r][2]);
+        for (int r = 0; r < 3; ++r) {          // gp[r] belongs to the face's vertex number ks[r]
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    if (ks[r] == q) c9[3 * q + c] = gp[r][c];
         }
         return;
     }
-    atomicAdd(gb + 3 * i0, gx0); atomicAdd(gb + 3 * i0 + 1, gy0); atomicAdd(gb + 3 * i0 + 2, dz0);
-    atomicAdd(gb + 3 * i1, gx1); atomicAdd(gb + 3 * i1 + 1, gy1); atomicAdd(gb + 3 * i1 + 2, dz1);
-    atomicAdd(gb + 3 * i2, gx2); atomicAdd(gb + 3 * i2 + 1, gy2); atomicAdd(gb + 3 * i2 + 2, dz2);
+    c9[0] = gx0; c9[1] = gy0; c9[2] = dz0; c9[3] = gx1; c9[4] = gy1; c9[5] = dz1; c9[6] = gx2; c9[7] = gy2; c9[8] = dz2;
+}
+
+// One workgroup per 16x16-pixel tile, every thread walks its pixel's K layers.  The nine contributions of a fragment are
+// summed per FACE in an LDS table (open addressing on the face index) and one set of nine global atomics per (tile, face)
+// goes out -- what raster_bwd_kernel does for the specialised K = 1 path (round 2 issued nine global float atomics per
+// fragment: 20 ms per step once config 5's mesh fills the screen).  DET 0: float table + float global atomics; DET 1: the
+// bound pass of the deterministic variant (partials[block] = sum of |contributions|); DET 2: 64-bit fixed point with the
+// scale derived from that bound (gndc is then the int64 accumulator array).  A fragment that finds no slot within
+// kSoftProbe steps (K layers can bring more faces than the table holds) adds to global memory directly.
+constexpr int kSoftFaceSlots = 512;
+
+template <int DET>
+__global__ __launch_bounds__(256) void raster_k_bwd_kernel(const float *__restrict__ gbary, const float *__restrict__ gzb,
+                                                           const float *__restrict__ gdist, const int32_t *__restrict__ p2f,
+                                                           const float *__restrict__ ndc, const int32_t *__restrict__ faces,
+                                                           int B, int V, int S, int K, int clip, int persp, int tiles_x,
+                                                           float *__restrict__ gndc, const int32_t *__restrict__ frag_slot,
+                                                           float z_clip, const st3d_det::DetHeader *__restrict__ det,
+                                                           float *__restrict__ partials) {
+    typedef typename std::conditional<DET == 2, unsigned long long, float>::type acc_t;
+    __shared__ int s_key[kSoftFaceSlots];
+    __shared__ acc_t s_acc[DET == 1 ? 1 : kSoftFaceSlots][9];
+    __shared__ float s4[4];
+    const int tid = threadIdx.x;
+    if (DET != 1) {
+        for (int e = tid; e < kSoftFaceSlots; e += 256) s_key[e] = -1;
+        for (int e = tid; e < kSoftFaceSlots * 9; e += 256) (&s_acc[0][0])[e] = (acc_t)0;
+        __syncthreads();
+    }
+    const double dscale = DET == 2 ? det->scale : 1.0;
+    const size_t HW = (size_t)S * S;
+    const int b = blockIdx.y;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int yi = ty * 16 + (tid >> 4), xi = tx * 16 + (tid & 15);
+    const float *vb = ndc + (size_t)b * V * 3;
+    float bound = 0.f;
+    if (yi < S && xi < S) {
+        const size_t pix = (size_t)b * HW + (size_t)yi * S + xi;
+        for (int k = 0; k < K; ++k) {
+            const size_t i = pix * K + k;
+            const int f = p2f[i];
+            if (f < 0) continue;
+            float c9[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            raster_k_frag_grad(gbary, gzb, gdist, vb, faces, S, clip, persp, frag_slot, z_clip, i, f, xi, yi, c9);
+            if (DET == 1) {
+#pragma unroll
+                for (int c = 0; c < 9; ++c) bound += fabsf(c9[c]);
+                continue;
+            }
+            int slot = (int)(((unsigned)f * 2654435761u) >> 23) & (kSoftFaceSlots - 1);
+            bool found = false;
+            for (int tries = 0; tries < kSoftProbe; ++tries) {
+                const int prev = atomicCAS(&s_key[slot], -1, f);
+                if (prev == -1 || prev == f) { found = true; break; }
+                slot = (slot + 1) & (kSoftFaceSlots - 1);
+            }
+#pragma unroll
+            for (int c = 0; c < 9; ++c) {
+                const size_t o = (size_t)b * V * 3 + 3 * (size_t)faces[3 * f + c / 3] + (c % 3);
+                if (DET == 2) {
+                    const unsigned long long q = (unsigned long long)st3d_det::det_quantise(c9[c], dscale);
+                    if (found) atomicAdd(reinterpret_cast<unsigned long long *>(&s_acc[slot][c]), q);
+                    else atomicAdd(reinterpret_cast<unsigned long long *>(gndc) + o, q);
+                } else {
+                    if (found) atomicAdd(reinterpret_cast<float *>(&s_acc[slot][c]), c9[c]);
+                    else atomicAdd(gndc + o, c9[c]);
+                }
+            }
+        }
+    }
+    if (DET == 1) {
+        const float t = st3d_det::det_block_sum(bound, s4);
+        if (tid == 0) partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = t;
+        return;
+    }
+    __syncthreads();
+    for (int e = tid; e < kSoftFaceSlots * 9; e += 256) {
+        const int slot = e / 9, c = e - slot * 9;
+        const int fk = s_key[slot];
+        if (fk < 0) continue;
+        const acc_t v = s_acc[slot][c];
+        if (v == (acc_t)0) continue;
+        const size_t o = (size_t)b * V * 3 + 3 * (size_t)faces[3 * fk + c / 3] + (c % 3);
+        if (DET == 2) atomicAdd(reinterpret_cast<unsigned long long *>(gndc) + o, (unsigned long long)v);
+        else atomicAdd(gndc + o, (float)v);
+    }
 }
 
 template <int K>
@@ -672,7 +823,7 @@ extern "C" int st3d_shade_soft_fwd(const int32_t *pix_to_face, const float *bary
                background[1], background[2]};
     const size_t n = (size_t)B * S * S;
     soft_shade_kernel<0><<<st3d::cdiv((long)n, 256), 256, 0, st3d::as_stream(stream)>>>(a, rgb, alpha, nullptr, nullptr, nullptr,
-                                                                                        nullptr, nullptr);
+                                                                                        nullptr, nullptr, 0, nullptr);
     ST3D_LAUNCH_CHECK();
     return ST3D_OK;
 }
@@ -687,9 +838,47 @@ extern "C" int st3d_shade_soft_bwd(const float *grad_rgb, const int32_t *pix_to_
     ST3D_CHECK_ARG(B > 0 && S > 0 && T > 1 && K >= 1 && sigma > 0.f && gamma > 0.f);
     SoftArgs a{pix_to_face, bary, zbuf, dists, verts_uvs, faces_uvs, texture, B, S, T, K, sigma, gamma, background[0],
                background[1], background[2]};
-    const size_t n = (size_t)B * S * S;
-    soft_shade_kernel<1><<<st3d::cdiv((long)n, 256), 256, 0, st3d::as_stream(stream)>>>(a, nullptr, nullptr, grad_rgb, grad_texture,
-                                                                                        grad_bary, grad_zbuf, grad_dists);
+    const int tiles = (S + 15) / 16;
+    soft_shade_kernel<1><<<dim3(tiles * tiles, B), 256, 0, st3d::as_stream(stream)>>>(a, nullptr, nullptr, grad_rgb, grad_texture,
+                                                                                      grad_bary, grad_zbuf, grad_dists, tiles, nullptr);
+    ST3D_LAUNCH_CHECK();
+    return ST3D_OK;
+}
+
+namespace { constexpr int kSoftDetPartials = 1024; }
+
+extern "C" size_t st3d_shade_soft_bwd_det_workspace_bytes(int T) {
+    return st3d_det::workspace_bytes((size_t)T * T * 3, kSoftDetPartials);
+}
+
+// st3d_shade_soft_bwd with a bitwise reproducible texture gradient (64-bit fixed-point accumulation, det.h; the bound of
+// every partial sum is sum |grad_rgb|: blend and bilinear weights are <= 1).  grad_texture is ACCUMULATED into.
+extern "C" int st3d_shade_soft_bwd_det(const float *grad_rgb, const int32_t *pix_to_face, const float *bary, const float *zbuf,
+                                       const float *dists, const float *verts_uvs, const int32_t *faces_uvs, const float *texture,
+                                       int B, int S, int T, int K, float sigma, float gamma, const float *background,
+                                       float *grad_texture, float *grad_bary, float *grad_zbuf, float *grad_dists,
+                                       void *workspace, size_t workspace_bytes, st3d_stream_t stream) {
+    ST3D_CHECK_ARG(grad_rgb && pix_to_face && bary && zbuf && dists && verts_uvs && faces_uvs && texture && background);
+    ST3D_CHECK_ARG(grad_texture && workspace);
+    ST3D_CHECK_ARG(B > 0 && S > 0 && T > 1 && K >= 1 && sigma > 0.f && gamma > 0.f);
+    ST3D_CHECK_ARG(workspace_bytes >= st3d_shade_soft_bwd_det_workspace_bytes(T) && ((uintptr_t)workspace & 15) == 0);
+    hipStream_t s = st3d::as_stream(stream);
+    SoftArgs a{pix_to_face, bary, zbuf, dists, verts_uvs, faces_uvs, texture, B, S, T, K, sigma, gamma, background[0],
+               background[1], background[2]};
+    auto *hdr = reinterpret_cast<st3d_det::DetHeader *>(workspace);
+    float *partials = st3d_det::partials_of(workspace);
+    long long *acc = st3d_det::accum_of(workspace, kSoftDetPartials);
+    const size_t npx = (size_t)B * 3 * S * S, nacc = (size_t)T * T * 3;
+    st3d_det::det_abs_sum_kernel<<<kSoftDetPartials, 256, 0, s>>>(grad_rgb, npx, partials);
+    ST3D_LAUNCH_CHECK();
+    st3d_det::det_scale_kernel<<<1, 256, 0, s>>>(partials, kSoftDetPartials, hdr);
+    ST3D_LAUNCH_CHECK();
+    ST3D_HIP(hipMemsetAsync(acc, 0, nacc * sizeof(long long), s));
+    const int tiles = (S + 15) / 16;
+    soft_shade_kernel<1, 1><<<dim3(tiles * tiles, B), 256, 0, s>>>(a, nullptr, nullptr, grad_rgb, reinterpret_cast<float *>(acc),
+                                                                   grad_bary, grad_zbuf, grad_dists, tiles, hdr);
+    ST3D_LAUNCH_CHECK();
+    st3d_det::det_convert_kernel<<<st3d::cdiv((long)nacc, 256), 256, 0, s>>>(acc, nacc, hdr, 1, grad_texture);
     ST3D_LAUNCH_CHECK();
     return ST3D_OK;
 }
@@ -702,10 +891,47 @@ extern "C" int st3d_raster_soft_bwd(const float *grad_bary, const float *grad_zb
     ST3D_CHECK_ARG(B > 0 && V > 0 && F > 0 && S > 0 && K >= 1);
     hipStream_t s = st3d::as_stream(stream);
     ST3D_HIP(hipMemsetAsync(grad_verts_ndc, 0, (size_t)B * V * 3 * sizeof(float), s));
-    const size_t n = (size_t)B * S * S * K;
-    raster_k_bwd_kernel<<<st3d::cdiv((long)n, 256), 256, 0, s>>>(grad_bary, grad_zbuf, grad_dists, pix_to_face, verts_ndc, faces, B,
-                                                                  V, S, K, clip_bary, perspective_correct, grad_verts_ndc,
-                                                                  frag_slot, z_clip);
+    const int tiles = (S + 15) / 16;
+    raster_k_bwd_kernel<0><<<dim3(tiles * tiles, B), 256, 0, s>>>(grad_bary, grad_zbuf, grad_dists, pix_to_face, verts_ndc, faces, B,
+                                                                  V, S, K, clip_bary, perspective_correct, tiles, grad_verts_ndc,
+                                                                  frag_slot, z_clip, nullptr, nullptr);
+    ST3D_LAUNCH_CHECK();
+    return ST3D_OK;
+}
+
+extern "C" size_t st3d_raster_soft_bwd_det_workspace_bytes(int B, int V, int S) {
+    const size_t tiles = (size_t)((S + 15) / 16);
+    return st3d_det::workspace_bytes((size_t)B * V * 3, tiles * tiles * B);
+}
+
+// st3d_raster_soft_bwd with a bitwise reproducible result (fixed-point accumulation, det.h): a first pass bounds the
+// partial sums, the second accumulates.
+extern "C" int st3d_raster_soft_bwd_det(const float *grad_bary, const float *grad_zbuf, const float *grad_dists,
+                                        const int32_t *pix_to_face, const float *verts_ndc, const int32_t *faces, int B, int V,
+                                        int F, int S, int K, int clip_bary, int perspective_correct, const int32_t *frag_slot,
+                                        float z_clip, float *grad_verts_ndc, void *workspace, size_t workspace_bytes,
+                                        st3d_stream_t stream) {
+    ST3D_CHECK_ARG(pix_to_face && verts_ndc && faces && grad_verts_ndc && workspace && (grad_bary || grad_zbuf || grad_dists));
+    ST3D_CHECK_ARG(B > 0 && V > 0 && F > 0 && S > 0 && K >= 1);
+    ST3D_CHECK_ARG(workspace_bytes >= st3d_raster_soft_bwd_det_workspace_bytes(B, V, S) && ((uintptr_t)workspace & 15) == 0);
+    hipStream_t s = st3d::as_stream(stream);
+    const int tiles = (S + 15) / 16;
+    const size_t np = (size_t)tiles * tiles * B, nacc = (size_t)B * V * 3;
+    auto *hdr = reinterpret_cast<st3d_det::DetHeader *>(workspace);
+    float *partials = st3d_det::partials_of(workspace);
+    long long *acc = st3d_det::accum_of(workspace, np);
+    raster_k_bwd_kernel<1><<<dim3(tiles * tiles, B), 256, 0, s>>>(grad_bary, grad_zbuf, grad_dists, pix_to_face, verts_ndc, faces, B,
+                                                                  V, S, K, clip_bary, perspective_correct, tiles, nullptr, frag_slot,
+                                                                  z_clip, nullptr, partials);
+    ST3D_LAUNCH_CHECK();
+    st3d_det::det_scale_kernel<<<1, 256, 0, s>>>(partials, (int)np, hdr);
+    ST3D_LAUNCH_CHECK();
+    ST3D_HIP(hipMemsetAsync(acc, 0, nacc * sizeof(long long), s));
+    raster_k_bwd_kernel<2><<<dim3(tiles * tiles, B), 256, 0, s>>>(grad_bary, grad_zbuf, grad_dists, pix_to_face, verts_ndc, faces, B,
+                                                                  V, S, K, clip_bary, perspective_correct, tiles,
+                                                                  reinterpret_cast<float *>(acc), frag_slot, z_clip, hdr, nullptr);
+    ST3D_LAUNCH_CHECK();
+    st3d_det::det_convert_kernel<<<st3d::cdiv((long)nacc, 256), 256, 0, s>>>(acc, nacc, hdr, 0, grad_verts_ndc);
     ST3D_LAUNCH_CHECK();
     return ST3D_OK;
 }

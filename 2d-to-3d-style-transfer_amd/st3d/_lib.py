@@ -52,6 +52,13 @@ SIGNATURES = {
                                     c_float, c_float, ctypes.POINTER(c_float), c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
     "st3d_raster_soft_bwd": (c_int, [c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_i32p, c_int, c_int, c_int, c_int, c_int, c_int,
                                      c_int, c_i32p, c_float, c_f32p, c_stream]),
+    "st3d_shade_soft_bwd_det_workspace_bytes": (c_size, [c_int]),
+    "st3d_shade_soft_bwd_det": (c_int, [c_f32p, c_i32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_int, c_int, c_int, c_int,
+                                        c_float, c_float, ctypes.POINTER(c_float), c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_void_p,
+                                        c_size, c_stream]),
+    "st3d_raster_soft_bwd_det_workspace_bytes": (c_size, [c_int, c_int, c_int]),
+    "st3d_raster_soft_bwd_det": (c_int, [c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_i32p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                         c_int, c_i32p, c_float, c_f32p, ctypes.c_void_p, c_size, c_stream]),
     "st3d_apply_background": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_f32p, c_stream]),
     "st3d_conv3x3_packed_floats": (c_size, [c_int, c_int]),
     "st3d_conv3x3_pack": (c_int, [c_f32p, c_int, c_int, c_f32p, c_f32p, c_stream]),

@@ -17,9 +17,9 @@ def _f32c(t):
     return t.detach().to(F32).contiguous()
 
 
-# The texture / vertex gradient scatters of the render backward accumulate in 64-bit fixed point (csrc/det.h): bitwise
-# reproducible from run to run, and measured no slower than the float-atomic kernels (0.128 vs 0.137 ms for the texture
-# scatter of config 2), so it is the default.  set_deterministic(False) / ST3D_DETERMINISTIC=0 selects the float atomics.
+# The texture / vertex gradient scatters of the render backward -- the specialised K = 1 path and, since round 3, the
+# general soft path -- accumulate in 64-bit fixed point (csrc/det.h): bitwise reproducible from run to run, and measured
+# no slower than the float-atomic kernels (0.128 vs 0.137 ms for the texture scatter of config 2), so it is the default.  set_deterministic(False) / ST3D_DETERMINISTIC=0 selects the float atomics.
 _DETERMINISTIC = os.environ.get("ST3D_DETERMINISTIC", "1") not in ("", "0")
 
 
@@ -274,6 +274,13 @@ def shade_soft_bwd(grad_rgb, frag, verts_uvs, faces_uvs_i32, texture, sigma=1e-4
     gb = torch.empty((B, S, S, K, 3), dtype=F32, device=dev) if want_geometry else None
     gz = torch.empty((B, S, S, K), dtype=F32, device=dev) if want_geometry else None
     gd = torch.empty((B, S, S, K), dtype=F32, device=dev) if want_geometry else None
+    if _DETERMINISTIC and gt is not None:       # fixed-point texture scatter: bitwise reproducible (st3d_shade_soft_bwd_det)
+        nb = _lib.load().st3d_shade_soft_bwd_det_workspace_bytes(T)
+        ws = torch.empty(((nb + 15) // 16 * 4,), dtype=F32, device=dev)
+        call("st3d_shade_soft_bwd_det", dptr(grad_rgb.contiguous(), F32), dptr(p2f, I32), dptr(bary, F32), dptr(zbuf, F32),
+             dptr(dists, F32), dptr(verts_uvs, F32), dptr(faces_uvs_i32, I32), dptr(texture, F32), B, S, T, K, float(sigma),
+             float(gamma), _bg3(background), dptr(gt), dptr(gb), dptr(gz), dptr(gd), dptr(ws), nb, stream_ptr())
+        return gt, ((gb, gz, gd) if want_geometry else None)
     call("st3d_shade_soft_bwd", dptr(grad_rgb.contiguous(), F32), dptr(p2f, I32), dptr(bary, F32), dptr(zbuf, F32),
          dptr(dists, F32), dptr(verts_uvs, F32), dptr(faces_uvs_i32, I32), dptr(texture, F32), B, S, T, K, float(sigma),
          float(gamma), _bg3(background), dptr(gt), dptr(gb), dptr(gz), dptr(gd), stream_ptr())
@@ -285,6 +292,14 @@ def raster_soft_bwd(grads, p2f, verts_ndc, faces_i32, clip_bary, perspective_cor
     B, V, _ = verts_ndc.shape
     S, K = p2f.shape[1], p2f.shape[3]
     g = torch.empty((B, V, 3), dtype=F32, device=verts_ndc.device)
+    if _DETERMINISTIC:                          # fixed-point vertex scatter (st3d_raster_soft_bwd_det)
+        nb = _lib.load().st3d_raster_soft_bwd_det_workspace_bytes(B, V, S)
+        ws = torch.empty(((nb + 15) // 16 * 4,), dtype=F32, device=verts_ndc.device)
+        call("st3d_raster_soft_bwd_det", dptr(gb, F32), dptr(gz, F32), dptr(gd, F32), dptr(p2f, I32), dptr(verts_ndc, F32),
+             dptr(faces_i32, I32), B, V, faces_i32.shape[0], S, K, 1 if clip_bary else 0, 1 if perspective_correct else 0,
+             dptr(slots, I32) if slots is not None else None, float(z_clip) if z_clip is not None else 0.0, dptr(g), dptr(ws), nb,
+             stream_ptr())
+        return g
     call("st3d_raster_soft_bwd", dptr(gb, F32), dptr(gz, F32), dptr(gd, F32), dptr(p2f, I32), dptr(verts_ndc, F32),
          dptr(faces_i32, I32), B, V, faces_i32.shape[0], S, K, 1 if clip_bary else 0, 1 if perspective_correct else 0,
          dptr(slots, I32) if slots is not None else None, float(z_clip) if z_clip is not None else 0.0, dptr(g), stream_ptr())

@@ -172,6 +172,21 @@ int st3d_raster_soft_bwd(const float *grad_bary, const float *grad_zbuf, const f
                          int S, int K, int clip_bary, int perspective_correct,
                          const int32_t *frag_slot /* from the clipped forward, or NULL */, float z_clip,
                          float *grad_verts_ndc, st3d_stream_t stream);
+/* The two scatters above with bitwise reproducible results: the same per-tile LDS binning (per texel / per face) in
+ * 64-bit fixed point (csrc/det.h), like st3d_shade_bwd_det / st3d_raster_bwd_det for the specialised K = 1 path.
+ * grad_texture must be given (it is accumulated into); workspace 16-byte aligned.  A non-finite input gradient gives a
+ * NaN result (never a laundered finite one). */
+size_t st3d_shade_soft_bwd_det_workspace_bytes(int T);
+int st3d_shade_soft_bwd_det(const float *grad_rgb, const int32_t *pix_to_face, const float *bary, const float *zbuf,
+                            const float *dists, const float *verts_uvs, const int32_t *faces_uvs, const float *texture,
+                            int B, int S, int T, int K, float sigma, float gamma, const float *background,
+                            float *grad_texture, float *grad_bary, float *grad_zbuf, float *grad_dists,
+                            void *workspace, size_t workspace_bytes, st3d_stream_t stream);
+size_t st3d_raster_soft_bwd_det_workspace_bytes(int B, int V, int S);
+int st3d_raster_soft_bwd_det(const float *grad_bary, const float *grad_zbuf, const float *grad_dists,
+                             const int32_t *pix_to_face, const float *verts_ndc, const int32_t *faces, int B, int V, int F,
+                             int S, int K, int clip_bary, int perspective_correct, const int32_t *frag_slot, float z_clip,
+                             float *grad_verts_ndc, void *workspace, size_t workspace_bytes, st3d_stream_t stream);
 
 /* apply_background, utils.py:19-30: out = img*mask + bg*(1-mask); bg (B,3,S,S) or, with
  * bg_batch == 1, one (3,S,S) image broadcast over the batch.  Optional grad path is the

@@ -891,6 +891,24 @@ def test_graph_replay_of_the_loss_step_is_bitwise_identical(mods, vgg):
     finally:
         plan.use_graph(False)
     assert vals[0][0] == vals[1][0] == vals[2][0] and torch.equal(vals[0][1], vals[2][1])
+    # a style target with a different batch stride (one shared image -> one image per view) after the capture: the
+    # captured launch indexed the style Grams with the old stride -- set_style now drops the graph
+    sty_b = torch.rand(B, 3, S, S, generator=g).to(dev)
+
+    def seq(graph):
+        plan.use_graph(graph)
+        out = []
+        try:
+            plan.set_content(con[0], force=True)
+            for style in (sty, sty, sty, sty_b, sty_b, sty_b, sty, sty):
+                plan.set_style(style, B, force=True)
+                loss, grad = plan.loss(imgs[1], 1e6, 1.0)
+                out.append((loss.clone(), grad.clone()))
+        finally:
+            plan.use_graph(False)
+        return out
+    for (l0, g0), (l1, g1) in zip(seq(False), seq(True)):
+        assert torch.equal(l0, l1) and torch.equal(g0, g1)
 
 
 def test_plan_cache_is_bounded_and_a_foreign_device_pointer_is_refused(mods, monkeypatch):

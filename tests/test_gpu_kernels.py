@@ -625,6 +625,62 @@ def test_soft_shade_forward_and_backward_match_oracle(dev, ops, cow, K, blur, si
     assert rel_v <= 5e-5, rel_v
 
 
+@pytest.mark.parametrize("K,blur,near", [(1, 0.0, True), (4, 3e-4, False), (8, 1e-3, True)])
+def test_soft_backward_scatters_fixed_point_vs_float_atomics(dev, ops, cow, K, blur, near):
+    """Round 3: the general path's two scatters (texture: per-tile texel table; vertices: per-tile face table) in both
+    modes.  Fixed point (the default): bitwise reproducible; float atomics: equal to it within their own run-to-run spread.
+    128^2 with up to 8 layers overflows the 2048-texel / 512-face tables of a tile, so the direct-to-global path of a
+    contribution that finds no slot is exercised; `near` puts the camera inside the cow's bounding sphere (clipped faces,
+    faces that cover many tiles -- the shape of BASELINE config 5 after its vertices reach the camera).  A NaN upstream
+    gradient comes out as NaN in both modes."""
+    from oracle import render_ref as rr
+    S, Tn, B = 128, 64, 2
+    if near:
+        R, T = rr.look_at_view_transform(0.8, [10.0, -20.0], [35.0, 140.0], at=(0, 0.10, 0.25))
+    else:
+        R, T = _cams(B, seed=11)
+    rng = np.random.default_rng(2)
+    verts = torch.from_numpy(cow["verts"]).to(dev)
+    faces = torch.from_numpy(cow["faces"]).to(dev)
+    uvs = torch.from_numpy(cow["verts_uvs"]).to(dev)
+    fuv = torch.from_numpy(cow["faces_uvs"]).to(dev)
+    texd = torch.from_numpy(rng.random((Tn, Tn, 3), dtype=np.float32)).to(dev)
+    ndc = ops.project_verts(verts, torch.from_numpy(R).to(dev), torch.from_numpy(T).to(dev))
+    clip = blur > 0
+    out = ops.raster_soft_fwd(ndc, faces, S, K, blur, clip, z_clip=0.5)
+    frag, slots = out[:4], out[4]
+    assert float((frag[0] >= 0).float().mean()) > 0.05
+    g = torch.from_numpy(rng.standard_normal((B, 3, S, S)).astype(np.float32)).to(dev)
+
+    def both():
+        gt, geo = ops.shade_soft_bwd(g, frag, uvs, fuv, texd, 1e-4, 1e-4, (1.0, 1.0, 1.0))
+        gv = ops.raster_soft_bwd(geo, frag[0], ndc, faces, clip, slots=slots, z_clip=0.5)
+        return gt, gv
+    try:
+        assert ops.is_deterministic()
+        t1, v1 = both()
+        t2, v2 = both()
+        assert torch.equal(t1, t2) and torch.equal(v1, v2)
+        ops.set_deterministic(False)
+        ta, va = both()
+        tb, vb = both()
+        spread_t = float((ta - tb).norm() / ta.norm())
+        spread_v = float((va - vb).norm() / va.norm())
+        assert float((t1 - ta).norm() / ta.norm()) <= max(3 * spread_t, 2e-6)
+        assert float((v1 - va).norm() / va.norm()) <= max(3 * spread_v, 2e-5)
+        gn = g.clone()
+        covered = (frag[0][0, ..., 0] >= 0).nonzero()
+        y, x = [int(v) for v in covered[covered.shape[0] // 2]]
+        gn[0, 2, y, x] = float("nan")
+        for det in (True, False):
+            ops.set_deterministic(det)
+            gt, geo = ops.shade_soft_bwd(gn, frag, uvs, fuv, texd, 1e-4, 1e-4, (1.0, 1.0, 1.0))
+            assert not torch.isfinite(gt).all()
+            assert not torch.isfinite(ops.raster_soft_bwd(geo, frag[0], ndc, faces, clip, slots=slots, z_clip=0.5)).all()
+    finally:
+        ops.set_deterministic(True)
+
+
 @pytest.mark.parametrize("K,blur,cull,persp", [(1, 0.0, True, True), (2, 0.0, False, False), (4, 5e-4, True, False)])
 def test_soft_raster_cull_backfaces_and_perspective_correct_flags(dev, ops, cow, K, blur, cull, persp):
     """RasterizationSettings.cull_backfaces / perspective_correct=False on the general kernels: fragments bit-exact vs
