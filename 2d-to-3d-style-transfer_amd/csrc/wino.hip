@@ -86,9 +86,16 @@ constexpr int EX4_FLOATS = 2 * 4 * 64 * 32;       // [2 j][4 a][64 co][32 tiles]
 constexpr int SMEM4_FLOATS = EX4_FLOATS > 3 * P4_STAGE ? EX4_FLOATS : 3 * P4_STAGE;      // 64 KB: two workgroups per CU use 128 of its 160 KB
 
 // GATE: 0 = plain outputs, 1 = outputs zeroed where a.gate <= 0, 2 = a.addc * (a.gate - a.addt) added first (EPI 0 only)
-template <int MODE, int EPI, int DBG = 0, int GATE = 0>
-__global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
-    __shared__ __attribute__((aligned(16))) float smem[SMEM4_FLOATS];
+// MH: 32-cout halves per workgroup.  2 (what ships): 64 cout, 128 accumulators, two workgroups per CU.  1 (round 3, the
+// short-K experiment, lab builds only): 32 cout, 64 accumulators (149-157 VGPRs) and a 32 KB exchange, so THREE workgroups
+// fit a CU -- two can be inside their K loops while the third is between tiles -- at the price of one MFMA per B operand
+// instead of two.  Measured 7-12 % slower on every VGG shape (see launch_wino4).
+template <int MODE, int EPI, int DBG = 0, int GATE = 0, int MH = 2>
+__global__ __launch_bounds__(NT4, MH == 1 ? 3 : 2) void wino4_kernel(const WinoArgs a) {
+    constexpr int BCOH = 32 * MH;              // cout per workgroup
+    constexpr int EXF = 2 * 4 * BCOH * 32;     // exchange floats [2 j][4 a][BCOH co][32 tiles]
+    constexpr int SMEMF = EXF > 3 * P4_STAGE ? EXF : 3 * P4_STAGE;
+    __shared__ __attribute__((aligned(16))) float smem[SMEMF];
     float *sP = smem;                          // [3][KS4][PR4][PCP]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wa = tid >> 6;  // wave = row a of the Winograd domain
@@ -111,7 +118,7 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
     const int tile_y = pt % a.tiles_y;
     const int n = pt / a.tiles_y;
     int x0 = tile_x * T4_COLS, y0 = tile_y * T4_ROWS;
-    const int co0 = ct * BCO;
+    const int co0 = ct * BCOH;
     if (DBG == 2) { x0 = 32; y0 = 8; }       // diagnostic: every workgroup reads the same (cache-resident) patch
     const int H = a.H, W = a.W;
     const size_t HW = (size_t)H * W;
@@ -153,9 +160,11 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
     if (UNPOOL)
         ridx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.idx + (size_t)n * a.Cin * in_plane), 0, img_bytes / 4, 0x00020000);
     const int nsub = a.Cin / KC;
+    // (the pack groups 64 couts: a 32-cout workgroup reads half `ct & 1` of group ct >> 1)
+    const int ct64 = MH == 2 ? ct : (ct >> 1), uhalf = MH == 2 ? 0 : (ct & 1);
     const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(a.U + (size_t)ct * nsub * 4096), 0, (unsigned)((size_t)nsub * 4096 * 4), 0x00020000);
-    const unsigned uvoff0 = (unsigned)((wa * 64 + lane) * 32), uvoff1 = (unsigned)(((wa + 4) * 64 + lane) * 32);
+        const_cast<float *>(a.U + (size_t)ct64 * nsub * 4096), 0, (unsigned)((size_t)nsub * 4096 * 4), 0x00020000);
+    const unsigned uvoff0 = (unsigned)(((wa + 4 * uhalf) * 64 + lane) * 32), uvoff1 = (unsigned)(((wa + 4) * 64 + lane) * 32);
 
     f32x4 xv[IPT];
     f32x4 xa[MODE == 1 ? IPT : 1];
@@ -248,21 +257,19 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
         }
     };
 
-    f32x16 acc[2][4];      // [cout half][b]
-#pragma unroll
-    for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mh][q][r] = 0.f;
+    // [cout half][b].  Never zeroed: the first eight MFMAs of the tile (stage 0, sub-chunk 0, k-step 0) take the constant 0
+    // as their C operand (W4_MFMA0) -- 128 v_mov per lane and tile less, all of them paid in matrix-pipe time (round 3)
+    f32x16 acc[MH][4];
 
-    struct Uop { f32x4 h[2][2]; };             // [cout half][ks] -> 4 floats (q)
+    struct Uop { f32x4 h[MH][2]; };            // [cout half][ks] -> 4 floats (q)
     auto uload = [&](int sub, Uop &u) __attribute__((always_inline)) {
         const unsigned so = (unsigned)min(sub, nsub - 1) * 16384u;
         u.h[0][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, uvoff0, so, 0));
         u.h[0][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, uvoff0 + 16, so, 0));
-        u.h[1][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, uvoff1, so, 0));
-        u.h[1][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, uvoff1 + 16, so, 0));
+        if (MH == 2) {
+            u.h[MH - 1][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, uvoff1, so, 0));
+            u.h[MH - 1][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, uvoff1 + 16, so, 0));
+        }
     };
 
     gload(0);
@@ -303,8 +310,14 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
 
 #define W4_MFMA(u, bv, ks)                                                                                      \
     _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                             \
-        acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.h[0][ks][q], bv.v[ks][q], acc[0][q], 0, 0, 0);        \
-        acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.h[1][ks][q], bv.v[ks][q], acc[1][q], 0, 0, 0);        \
+        _Pragma("unroll") for (int h_ = 0; h_ < MH; ++h_)                                                       \
+            acc[h_][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.h[h_][ks][q], bv.v[ks][q], acc[h_][q], 0, 0, 0); \
+    }
+#define W4_MFMA0(u, bv)                                                                                         \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                             \
+        const f32x16 zero_ = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};           \
+        _Pragma("unroll") for (int h_ = 0; h_ < MH; ++h_)                                                       \
+            acc[h_][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.h[h_][0][q], bv.v[0][q], zero_, 0, 0, 0);        \
     }
     // one stage = 8 input channels = sub-chunks s0 (operands ready in ua / bcur) and s1, as four quarters of 8 MFMAs.  Each
     // quarter's memory / LDS / VALU work (which prepares LATER quarters) is INTERLEAVED with its MFMAs by
@@ -326,8 +339,9 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
 #endif
     // The ring position is a compile-time constant of each copy of the stage (the loop is unrolled by the ring depth, 3):
     // every LDS address is the lane's base plus an immediate, no per-stage address arithmetic on the vector ALU.
-    auto stage = [&](int c, auto PBc) __attribute__((always_inline)) {
+    auto stage = [&](int c, auto PBc, auto FIRSTc) __attribute__((always_inline)) {
         constexpr int pb = decltype(PBc)::value, pb1 = (pb + 1) % 3, pb2 = (pb + 2) % 3;
+        constexpr bool first = decltype(FIRSTc)::value;     // the tile's first stage: its first MFMAs start the accumulators
         Vals staged;
 #pragma unroll
         for (int sc = 0; sc < NSUB4; ++sc) {          // sub-chunk sc: its operands are ready in (ua | ub) / (bcur | bnext) by parity
@@ -345,46 +359,49 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
             // sub-chunk's filter operands and patch reads (the last one reads the NEXT stage's buffer, staged a barrier ago),
             // and in the last sub-chunk the gates of the items that arrived meanwhile
             __builtin_amdgcn_sched_barrier(0);
-            W4_MFMA(ucur, bc, 0)
+            if (first && sc == 0) { W4_MFMA0(ucur, bc) } else { W4_MFMA(ucur, bc, 0) }
             if (sc == 0) gload(min(c + 2, nstages - 1));
             uload(NSUB4 * c + sc + ST3D_WINO_UDEPTH, unext);
             if (sc + 1 < NSUB4) pread(pb, sc + 1, draw);
             else pread(pb1, 0, draw);
             if (sc == NSUB4 - 1) lgate(staged);
-            _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {
+            _Pragma("unroll") for (int i_ = 0; i_ < 4 * MH; ++i_) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x120, ST3D_WINO_SCHED == 0 ? 1 : 2, 0);
-                if (MODE != 0 && sc == NSUB4 - 1) __builtin_amdgcn_sched_group_barrier(0x002, KS4 / 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x120, (ST3D_WINO_SCHED == 0 ? 1 : 2) * (3 - MH), 0);
+                if (MODE != 0 && sc == NSUB4 - 1) __builtin_amdgcn_sched_group_barrier(0x002, (KS4 / 2) * (3 - MH), 0);
             }
             // transform quarter: the k-steps 1 || the next sub-chunk's B operands (VALU), the ring writes in the last one
             __builtin_amdgcn_sched_barrier(0);
             W4_MFMA(ucur, bc, 1)
             bcompute(draw, bn);
             if (sc == NSUB4 - 1) lwrite(pb2, staged);
-            _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {
+            _Pragma("unroll") for (int i_ = 0; i_ < 4 * MH; ++i_) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-                if (sc == NSUB4 - 1) __builtin_amdgcn_sched_group_barrier(0x200, KS4 / 8, 0);       // LDS writes
+                __builtin_amdgcn_sched_group_barrier(0x002, 2 * (3 - MH), 0);
+                if (sc == NSUB4 - 1) __builtin_amdgcn_sched_group_barrier(0x200, (KS4 / 8) * (3 - MH), 0);       // LDS writes
             }
         }
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
     };
-    int c = 0;
+    constexpr std::false_type kRest{};
+    stage(0, std::integral_constant<int, 0>{}, std::true_type{});
+    int c = 1;                                     // ring position of stage c is c % 3: the unrolled loop starts at 1
     for (; c + 3 <= nstages; c += 3) {
-        stage(c, std::integral_constant<int, 0>{});
-        stage(c + 1, std::integral_constant<int, 1>{});
-        stage(c + 2, std::integral_constant<int, 2>{});
+        stage(c, std::integral_constant<int, 1>{}, kRest);
+        stage(c + 1, std::integral_constant<int, 2>{}, kRest);
+        stage(c + 2, std::integral_constant<int, 0>{}, kRest);
     }
-    if (c < nstages) stage(c, std::integral_constant<int, 0>{});
-    if (c + 1 < nstages) stage(c + 1, std::integral_constant<int, 1>{});
+    if (c < nstages) stage(c, std::integral_constant<int, 1>{}, kRest);
+    if (c + 1 < nstages) stage(c + 1, std::integral_constant<int, 2>{}, kRest);
 #undef W4_ILV
 #undef W4_MFMA
+#undef W4_MFMA0
 
     if (DBG == 1) {                          // diagnostic: no epilogue (keeps the accumulators live with one store)
         float t = 0.f;
 #pragma unroll
-        for (int mh = 0; mh < 2; ++mh)
+        for (int mh = 0; mh < MH; ++mh)
 #pragma unroll
             for (int q = 0; q < 4; ++q) t += acc[mh][q][0];
         if (t == 12345.678f && a.y) a.y[0] = t;
@@ -398,19 +415,20 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
     float *ex = smem;
     // this thread's four biases are fetched NOW: a load issued between the stores below would have to wait for every
     // older store to complete (vmcnt counts loads and stores in order), serialising the four output items
-    float bias4[4];
+    constexpr int NIT = 2 * MH;            // output items per thread: 16 couts each
+    float bias4[NIT];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) bias4[it] = (a.bias && DBG != 4) ? a.bias[co0 + it * 16 + (tid >> 4)] : 0.f;
+    for (int it = 0; it < NIT; ++it) bias4[it] = (a.bias && DBG != 4) ? a.bias[co0 + it * 16 + (tid >> 4)] : 0.f;
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-        for (int mh = 0; mh < 2; ++mh)
+        for (int mh = 0; mh < MH; ++mh)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float z = jj == 0 ? (acc[mh][0][r] + acc[mh][1][r] + acc[mh][2][r])
                                         : (acc[mh][1][r] - acc[mh][2][r] - acc[mh][3][r]);
                 const int co = mh * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                ex[((jj * 4 + wa) * 64 + co) * 32 + l31] = z;
+                ex[((jj * 4 + wa) * BCOH + co) * 32 + l31] = z;
             }
     const int pair = tid & 15;                        // tiles 2 * pair, 2 * pair + 1 (same tile row)
     const int oy = y0 + 2 * (pair >> 3), ox = x0 + 4 * (pair & 7);
@@ -425,12 +443,12 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
     const unsigned item_bytes = (unsigned)(16 * HW * 4);
     // the consumer's ReLU gate, applied here (a.gate: the tensor this gradient belongs to): fetched now -- the accumulators
     // are dead, and a load issued between the stores below would queue behind them -- and used after the exchange
-    f32x4 gq[GATE >= 1 ? 4 : 1][2], tq[GATE == 2 ? 4 : 1][2];
+    f32x4 gq[GATE >= 1 ? NIT : 1][2], tq[GATE == 2 ? NIT : 1][2];
     if (GATE >= 1) {
         const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float *>(a.gate + (size_t)n * a.Cout * HW), 0, out_bytes, 0x00020000);
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
+        for (int it = 0; it < NIT; ++it) {
             gq[it][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, vo0, it * item_bytes, 0));
             gq[it][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, vo1, it * item_bytes, 0));
         }
@@ -439,7 +457,7 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
         const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float *>(a.addt + (size_t)n * a.Cout * HW), 0, out_bytes, 0x00020000);
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
+        for (int it = 0; it < NIT; ++it) {
             tq[it][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rt, vo0, it * item_bytes, 0));
             tq[it][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rt, vo1, it * item_bytes, 0));
         }
@@ -453,16 +471,17 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
         if (a.yidx) ryi = __builtin_amdgcn_make_buffer_rsrc(a.yidx + (size_t)n * a.Cout * HpWp, 0, (unsigned)(a.Cout * HpWp), 0x00020000);
         if (inb) vp = (unsigned)((((size_t)co0 + (tid >> 4)) * HpWp + (size_t)(oy >> 1) * Wp + (ox >> 1)) * 4);
     }
+    const float relu_floor = a.relu ? 0.f : -__builtin_inff();      // ReLU as max(v, floor) with a wave-uniform floor
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int col = it * 16 + (tid >> 4);         // cout within the workgroup's 64
+    for (int it = 0; it < NIT; ++it) {
+        const int col = it * 16 + (tid >> 4);         // cout within the workgroup's 32 * MH
         f32x2 z[2][4];
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
             for (int aa = 0; aa < 4; ++aa)
-                z[jj][aa] = *reinterpret_cast<const f32x2 *>(&ex[((jj * 4 + aa) * 64 + col) * 32 + 2 * pair]);
+                z[jj][aa] = *reinterpret_cast<const f32x2 *>(&ex[((jj * 4 + aa) * BCOH + col) * 32 + 2 * pair]);
         const float bsum = bias4[it];
         // y[i][jj] per tile t: i = 0: z0 + z1 + z2, i = 1: z1 - z2 - z3 (along a)
         float y[2][2][2];      // [tile][row i][col jj]
@@ -472,7 +491,7 @@ __global__ __launch_bounds__(NT4, 2) void wino4_kernel(const WinoArgs a) {
             for (int jj = 0; jj < 2; ++jj) {
                 float v0 = z[jj][0][t] + z[jj][1][t] + z[jj][2][t] + bsum;
                 float v1 = z[jj][1][t] - z[jj][2][t] - z[jj][3][t] + bsum;
-                if (GATE == 0 && a.relu) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }     // (gated launches are input-gradients: no ReLU)
+                if (GATE == 0) { v0 = __builtin_fmaxf(v0, relu_floor); v1 = __builtin_fmaxf(v1, relu_floor); }     // one v_max each (gated launches are input-gradients: no ReLU)
                 y[t][0][jj] = v0; y[t][1][jj] = v1;
             }
         if (DBG == 3 && y[0][0][0] != 12345.678f) continue;       // diagnostic: whole epilogue but no global stores
@@ -572,7 +591,16 @@ template <int MODE>
 int launch_wino4(WinoArgs a, hipStream_t s) {
     a.tiles_x = st3d::cdiv(a.W, T4_COLS);
     a.tiles_y = st3d::cdiv(a.H, T4_ROWS);
-    a.n_ct = a.Cout / BCO;
+#ifdef ST3D_LAB
+    // lab builds: ST3D_WINO_MH1_MAXK=k runs layers with at most k input channels on 32-cout workgroups, three per CU
+    // (MH = 1).  Measured in round 3 (tools/wino_layers.py) and NOT taken: 7-12 % slower on every VGG shape, conv1_2
+    // included -- one MFMA per B operand doubles the vector-ALU work per MFMA, which costs more than the third workgroup hides.
+    static const int mh1_maxk = [] { const char *e = getenv("ST3D_WINO_MH1_MAXK"); return e ? atoi(e) : 0; }();
+    const bool mh1 = a.Cin <= mh1_maxk;
+#else
+    constexpr bool mh1 = false;
+#endif
+    a.n_ct = a.Cout / (mh1 ? 32 : BCO);
     const long ntiles = (long)a.tiles_x * a.tiles_y * a.N;
     // block -> (pixel tile, cout tile): XCD-chunked for the full-resolution inputs (measured 1-6 % faster than dealing pixel
     // tiles round-robin: halo rows and the cout tiles' shared patch hit the XCD's L2), round-robin for the fused-unpool
@@ -597,6 +625,18 @@ int launch_wino4(WinoArgs a, hipStream_t s) {
         return ST3D_OK;
     }
     if (dbgmode == 2 && MODE == 0) { if (a.yp) wino4_kernel<0, 1, 2><<<(unsigned)blocks, NT4, 0, s>>>(a); else wino4_kernel<0, 0, 2><<<(unsigned)blocks, NT4, 0, s>>>(a); return ST3D_OK; }
+#endif
+#ifdef ST3D_LAB
+    if (mh1) {          // 32-cout workgroups, three per CU
+        if (a.yp) wino4_kernel<MODE, 1, 0, 0, 1><<<(unsigned)blocks, NT4, 0, s>>>(a);
+        else if (a.gate && a.addt) {
+            if (MODE != 0) { st3d::set_error("wino4: the content-target term rides on ungated input (MODE 0) only"); return ST3D_E_INVALID; }
+            wino4_kernel<0, 0, 0, 2, 1><<<(unsigned)blocks, NT4, 0, s>>>(a);
+        } else if (a.gate) wino4_kernel<MODE, 0, 0, 1, 1><<<(unsigned)blocks, NT4, 0, s>>>(a);
+        else wino4_kernel<MODE, 0, 0, 0, 1><<<(unsigned)blocks, NT4, 0, s>>>(a);
+        ST3D_LAUNCH_CHECK();
+        return ST3D_OK;
+    }
 #endif
     if (a.yp) wino4_kernel<MODE, 1><<<(unsigned)blocks, NT4, 0, s>>>(a);        // (forward: never gated)
     else if (a.gate && a.addt) {
