@@ -169,3 +169,24 @@ def test_raster_settings_and_blend_params_validation():
             RasterizationSettings(**bad)
     with pytest.raises(ValueError):
         BlendParams(gamma=0.0)
+
+
+def test_bench_accounting_helpers():
+    """bench.py's roofline arithmetic (no GPU): SURVEY.md 8d flop counts, the Gram forward's ISSUED fractions as gram.hip
+    computes them (blocks on / above the diagonal only: 3/4, 10/16 of 32x32 blocks; 10/16, 36/64 of 64x64 wave tiles --
+    the round-2 line priced single-tile layers at 100 % and printed a fraction of 1.08), and the guard that refuses to
+    print any fraction above 1."""
+    import bench
+    S, B = 512, 8
+    fwd = sum(bench.conv_alg_flops(m, S, 1) for m, *_ in bench.CONVS)
+    assert abs(fwd / 1e9 - 189.35) < 0.05                                    # forward to conv5_1 per view (SURVEY.md 8d)
+    gram = sum(bench.gram_alg_flops(m, S, 1) for m in bench.STYLE_TAPS)
+    assert abs(gram / 1e9 - 9.13) < 0.01
+    assert [bench.gram_fwd_issued_fraction(m) for m in (0, 5, 10, 19, 28)] == [0.75, 0.625, 0.625, 0.5625, 0.5625]
+    # the one launch that holds all five layers (module tag 99): flop-weighted sums
+    assert bench.gram_alg_flops(99, S, B) == sum(bench.gram_alg_flops(m, S, B) for m in bench.STYLE_TAPS)
+    issued = bench.gram_fwd_issued_flops(99, S, B)
+    assert abs(issued / 1e9 - (12.885 + 10.737 + 10.737 + 9.664 + 2.416)) < 0.01     # = the PMC-counted 46.44 GF of a step
+    bench.check_fractions({"roofline": {"frac": 0.79}, "kernels": {"a": {"mfma_frac": 1.0, "hbm_frac": None}}, "layers": [{"mfma_frac": 0.5}]})
+    with pytest.raises(AssertionError, match="mfma_frac"):
+        bench.check_fractions({"layers": [{"mfma_frac": 1.08}]})
