@@ -29,6 +29,7 @@ SOURCES = {
     "soft.hip": ["-ffp-contract=off"],
     "conv.hip": ["-fno-slp-vectorize"],   # the VALU conv1_1 kernels: SLP-packed v_pk_fma needs register-pair shuffles
     "wino.hip": ["-fno-slp-vectorize"],   # SLP-packed f32 (v_pk_*) needs register shuffles that cost matrix-pipe time
+    "wino43.hip": ["-fno-slp-vectorize"],
     "gram.hip": [],
     "tap0.hip": [],
     "loss.hip": ["-ffp-contract=off"],

@@ -75,7 +75,7 @@ __device__ __forceinline__ float det_block_sum(float v, float *s4) {      // 256
 
 // partials[block] = sum |x| over the block's grid-stride share (the bound of the texture scatters: every contribution is
 // a gradient value times blend and bilinear weights <= 1)
-static __global__ __launch_bounds__(256) void det_abs_sum_kernel(const float *__restrict__ x, size_t n, float *__restrict__ partials) {
+__attribute__((unused)) static __global__ __launch_bounds__(256) void det_abs_sum_kernel(const float *__restrict__ x, size_t n, float *__restrict__ partials) {
     __shared__ float s4[4];
     float acc = 0.f;
     const size_t stride = (size_t)gridDim.x * blockDim.x;

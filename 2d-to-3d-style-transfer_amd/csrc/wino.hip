@@ -514,8 +514,11 @@ __global__ __launch_bounds__(NT4, MH == 1 ? 3 : 2) void wino4_kernel(const WinoA
                     q1[e] = gq[it][1][e] > 0.f ? q1[e] : 0.f;
                 }
             }
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q0), ry, vo0, it * item_bytes, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q1), ry, vo1, it * item_bytes, 0);
+            // the item's channel step goes into the VECTOR offset and the scalar offset stays 0: with an SGPR scalar offset
+            // the compiler assumes a 16-byte store has read its data registers at issue and may reuse them at once; on
+            // gfx950 the last lanes of such a store were seen to pick up the next values (round 3, csrc/wino43.hip)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q0), ry, inb ? vo0 + it * item_bytes : kOob, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q1), ry, inb ? vo1 + it * item_bytes : kOob, 0, 0);
         }
         if (EPI == 1) {     // MaxPool2d(2,2): first maximum in row-major window order (ATen); two adjacent windows per lane
             f32x2 best; unsigned bidx = 0;

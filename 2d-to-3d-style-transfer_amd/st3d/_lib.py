@@ -80,6 +80,13 @@ SIGNATURES = {
                                        c_stream]),
     "st3d_wino_dgrad_chain": (c_int, [c_f32p, c_f32p, c_u8p, c_f32p, c_f32p, c_f32p, c_f32p, c_float, c_f32p, c_int, c_int, c_int,
                                       c_int, c_int, c_stream]),
+    "st3d_wino43_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "st3d_wino43_packed_floats": (c_size, [c_int, c_int]),
+    "st3d_wino43_pack": (c_int, [c_f32p, c_int, c_int, c_f32p, c_f32p, c_stream]),
+    "st3d_wino43_fwd": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_u8p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                c_stream]),
+    "st3d_wino43_dgrad_chain": (c_int, [c_f32p, c_u8p, c_f32p, c_f32p, c_f32p, c_float, c_f32p, c_int, c_int, c_int, c_int,
+                                        c_int, c_stream]),
     "st3d_maxpool2x2_fwd": (c_int, [c_f32p, c_f32p, c_u8p, c_int, c_int, c_int, c_int, c_stream]),
     "st3d_gram_workspace_bytes": (c_size, [c_int, c_int, c_int]),
     "st3d_gram_fwd": (c_int, [c_f32p, c_int, c_int, c_int, ctypes.c_void_p, c_size, c_f32p, c_stream]),

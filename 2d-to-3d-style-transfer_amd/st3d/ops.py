@@ -411,6 +411,37 @@ def wino_dgrad_chain(gy, ud, Cin, act=None, pool_idx=None, pooled=None, out_gate
     return gx
 
 
+def wino43_pack(w):
+    """w (Cout,Cin,3,3) -> (u_fwd, u_dgrad): F(4x4,3x3) filter packs (36 floats per weight, st3d_wino43_pack)."""
+    w = _f32c(w)
+    Cout, Cin = w.shape[:2]
+    n = _lib.load().st3d_wino43_packed_floats(Cout, Cin)
+    uf = torch.empty((n,), dtype=F32, device=w.device)
+    ud = torch.empty((n,), dtype=F32, device=w.device)
+    call("st3d_wino43_pack", dptr(w), Cout, Cin, dptr(uf), dptr(ud), stream_ptr())
+    return uf, ud
+
+
+def wino43_fwd(x, uf, bias, Cout, relu=True, pool=False, keep_full=True):
+    N, Cin, H, W = x.shape
+    y = torch.empty((N, Cout, H, W), dtype=F32, device=x.device) if (keep_full or not pool) else None
+    yp = torch.empty((N, Cout, H // 2, W // 2), dtype=F32, device=x.device) if pool else None
+    idx = torch.empty((N, Cout, H // 2, W // 2), dtype=U8, device=x.device) if pool else None
+    call("st3d_wino43_fwd", dptr(x.contiguous(), F32), dptr(uf, F32), dptr(bias, F32) if bias is not None else None, dptr(y),
+         dptr(yp), dptr(idx), N, Cin, Cout, H, W, 1 if relu else 0, stream_ptr())
+    return (y, yp, idx) if pool else y
+
+
+def wino43_dgrad_chain(gy, ud, Cin, pool_idx=None, out_gate=None, add_target=None, add_coef=0.0):
+    """One link of the producer-gated backward chain on the F(4x4,3x3) kernel (st3d_wino43_dgrad_chain)."""
+    N, Cout = gy.shape[:2]
+    H, W = (2 * gy.shape[2], 2 * gy.shape[3]) if pool_idx is not None else gy.shape[2:]
+    gx = torch.empty((N, Cin, H, W), dtype=F32, device=gy.device)
+    call("st3d_wino43_dgrad_chain", dptr(gy.contiguous(), F32), dptr(pool_idx, U8), dptr(ud, F32), dptr(out_gate, F32),
+         dptr(add_target, F32), float(add_coef), dptr(gx), N, Cin, Cout, H, W, stream_ptr())
+    return gx
+
+
 def maxpool2x2(y, want_idx=True):
     N, C, H, W = y.shape
     p = torch.empty((N, C, H // 2, W // 2), dtype=F32, device=y.device)

@@ -252,6 +252,19 @@ int st3d_wino_dgrad_unpool(const float *gy_pooled, const uint8_t *pool_idx, cons
 int st3d_wino_dgrad_chain(const float *gy, const float *act, const uint8_t *pool_idx, const float *pooled,
                           const float *u_dgrad, const float *out_gate, const float *add_target, float add_coef,
                           float *gx, int N, int Cin, int Cout, int H, int W, st3d_stream_t stream);
+/* The same convolutions as Winograd F(4x4,3x3) (csrc/wino43.hip, round 3): 2.25 instead of 4 MFMA-multiplies per output
+ * pixel, fp32 throughout (<= 1.3e-5 of the output scale against an fp64 convolution at K = 512).  Shapes: Cin >= 16,
+ * Cin % 8 == 0, Cout % 64 == 0 (both % 64 for the pack), H % 4 == 0, W % 64 == 0.  Own filter pack (36 floats per weight).
+ * st3d_wino43_dgrad_chain takes an already gated gradient (or, with pool_idx, the pooled-resolution gradient) exactly as
+ * st3d_wino_dgrad_chain does with act == pooled == NULL. */
+int st3d_wino43_supported(int Cin, int Cout, int H, int W);
+size_t st3d_wino43_packed_floats(int Cout, int Cin);
+int st3d_wino43_pack(const float *w, int Cout, int Cin, float *u_fwd, float *u_dgrad, st3d_stream_t stream);
+int st3d_wino43_fwd(const float *x, const float *u_fwd, const float *bias, float *y, float *y_pooled, uint8_t *pool_idx,
+                    int N, int Cin, int Cout, int H, int W, int relu, st3d_stream_t stream);
+int st3d_wino43_dgrad_chain(const float *gy, const uint8_t *pool_idx, const float *u_dgrad, const float *out_gate,
+                            const float *add_target, float add_coef, float *gx, int N, int Cin, int Cout, int H, int W,
+                            st3d_stream_t stream);
 /* MaxPool2d(2,2): y (N,C,H,W) -> p (N,C,H/2,W/2) (+ argmax idx, may be NULL) */
 int st3d_maxpool2x2_fwd(const float *y, float *p, uint8_t *idx, int N, int C, int H, int W,
                         st3d_stream_t stream);

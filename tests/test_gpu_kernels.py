@@ -534,6 +534,60 @@ def test_wino_fused_pool_and_unpool(dev, ops, N, Cin, Cout, H, W):
     _scale_close(gx, ref_gx, 6e-5, "wino dgrad_unpool")
 
 
+# ---------------------------------------------------------------------------- Winograd F(4x4,3x3) conv (round 3)
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(1, 64, 64, 4, 64), (2, 128, 64, 8, 64), (1, 256, 256, 16, 128), (1, 512, 512, 64, 64),
+                                             (2, 128, 256, 12, 192)])
+def test_wino43_fwd_and_chain_dgrad(dev, ops, N, Cin, Cout, H, W):
+    """F(4x4,3x3) kernel (csrc/wino43.hip) against an fp64 direct convolution at the SAME tolerance as the F(2x2,3x3)
+    kernel (3e-5 of the output scale forward, 5e-5 input-gradient; measured ~1e-5 at K = 512), the fused pool against the
+    separate pool kernel (bitwise), the producer-side output gate / content term and the fused unpool against the plain
+    launch on pre-processed operands (bitwise: same arithmetic), and against the F(2x2,3x3) kernel on the same inputs."""
+    torch.manual_seed(Cin + Cout + H)
+    x = torch.randn(N, Cin, H, W, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(Cout, Cin, 3, 3) * (2.0 / (Cin * 9)) ** 0.5).double()
+    b = (torch.randn(Cout) * 0.1).double()
+    pre = F.conv2d(x, w, b, padding=1)
+    y = F.relu(pre)
+    xd, bd = x.detach().float().to(dev), b.float().to(dev)
+    assert ops._lib.load().st3d_wino43_supported(Cin, Cout, H, W) == 1
+    uf, ud = ops.wino43_pack(w.float().to(dev))
+    yd = ops.wino43_fwd(xd, uf, bd, Cout, relu=True)
+    _scale_close(yd, y, 3e-5, "wino43 fwd")
+    _scale_close(ops.wino43_fwd(xd, uf, bd, Cout, relu=False), pre, 3e-5, "wino43 fwd (no relu)")
+    u2f, u2d = ops.wino_pack(w.float().to(dev))
+    _scale_close(yd, ops.wino_fwd(xd, u2f, bd, Cout, relu=True), 3e-5, "wino43 vs wino F(2x2,3x3)")
+    # fused pool
+    yf, pd, idx = ops.wino43_fwd(xd, uf, bd, Cout, relu=True, pool=True)
+    p2, idx2 = ops.maxpool2x2(yd)
+    assert torch.equal(yf, yd) and torch.equal(pd, p2) and torch.equal(idx, idx2)
+    nf, pd3, idx3 = ops.wino43_fwd(xd, uf, bd, Cout, relu=True, pool=True, keep_full=False)
+    assert nf is None and torch.equal(pd3, pd) and torch.equal(idx3, idx)
+    # input gradient of a pre-gated gradient
+    gy = torch.randn_like(y)
+    gate = (yd.cpu() > 0).double()
+    gyg = (gy * gate).float().to(dev)
+    gx = ops.wino43_dgrad_chain(gyg, ud, Cin)
+    ref_gx = torch.autograd.grad(pre, x, gy * gate)[0]
+    _scale_close(gx, ref_gx, 5e-5, "wino43 dgrad")
+    # producer-side gate of the NEXT link and the content term: bitwise the plain result post-processed
+    og = torch.randn(N, Cin, H, W).to(dev)
+    tgt = torch.randn(N, Cin, H, W).to(dev)
+    assert torch.equal(ops.wino43_dgrad_chain(gyg, ud, Cin, out_gate=og), torch.where(og > 0, gx, torch.zeros_like(gx)))
+    want = torch.where(og > 0, gx + 0.37 * (og - tgt), torch.zeros_like(gx))
+    assert torch.equal(ops.wino43_dgrad_chain(gyg, ud, Cin, out_gate=og, add_target=tgt, add_coef=0.37), want)
+    # fused unpool: pooled-resolution gradient + argmax == the plain launch on the scattered full-resolution gradient
+    gp = torch.randn(N, Cout, H // 2, W // 2).to(dev)
+    pidx = torch.randint(0, 4, (N, Cout, H // 2, W // 2), dtype=torch.uint8).to(dev)
+    up = torch.zeros(N, Cout, H, W, device=dev)
+    for k in range(4):
+        up[:, :, (k >> 1)::2, (k & 1)::2] = gp * (pidx == k).float()
+    assert torch.equal(ops.wino43_dgrad_chain(gp, ud, Cin, pool_idx=pidx), ops.wino43_dgrad_chain(up, ud, Cin))
+    assert torch.equal(ops.wino43_dgrad_chain(gp, ud, Cin, pool_idx=pidx, out_gate=og),
+                       ops.wino43_dgrad_chain(up, ud, Cin, out_gate=og))
+    # shapes outside the tiling are refused, not mis-computed
+    assert ops._lib.load().st3d_wino43_supported(Cin, Cout, H, W + 32) == 0 and ops._lib.load().st3d_wino43_supported(8, Cout, H, W) == 0
+
+
 # ---------------------------------------------------------------------------- general soft renderer (K faces / pixel, blur)
 @pytest.mark.parametrize("K,blur,clip", [(1, 0.0, False), (3, 0.0, False), (4, 2e-4, True), (8, 1e-3, True)])
 def test_soft_raster_matches_oracle(dev, ops, cow, K, blur, clip):

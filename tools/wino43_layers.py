@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""F(4x4,3x3) (csrc/wino43.hip) against F(2x2,3x3) (wino4_kernel) per VGG layer of one config-2 step (8 views, 512^2):
+forward (with the fused pool where the plan fuses it) and the chain input-gradient (pre-gated input, output gate; fused
+unpool where the plan has one).  ms and equivalent F(2x2,3x3)-issued fraction of the fp32-MFMA peak."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "2d-to-3d-style-transfer_amd"))
+import torch
+from st3d import ops
+B = int(os.environ.get("B", "8")); S = int(os.environ.get("S", "512"))
+dev = torch.device("cuda:0")
+# (name, Cin, Cout, divisor, pooled_after, grad_arrives_pooled)
+LAYERS = [("conv2_2", 128, 128, 2, True, True), ("conv3_1", 128, 256, 4, False, False), ("conv3_2", 256, 256, 4, False, False),
+          ("conv3_4", 256, 256, 4, True, True), ("conv4_1", 256, 512, 8, False, False), ("conv4_2", 512, 512, 8, False, False),
+          ("conv4_4", 512, 512, 8, True, True)]
+def timeit(fn, n=10):
+    for _ in range(2): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+tot2 = tot4 = 0.0
+for name, Cin, Cout, d, pooled, gpooled in LAYERS:
+    H = S // d
+    if not ops._lib.load().st3d_wino43_supported(Cin, Cout, H, H):
+        print(name, "not supported"); continue
+    torch.manual_seed(0)
+    x = torch.randn(B, Cin, H, H, device=dev).relu_()
+    w = torch.randn(Cout, Cin, 3, 3, device=dev) * (2.0 / (Cin * 9)) ** 0.5
+    b = torch.randn(Cout, device=dev) * 0.1
+    uf2, ud2 = ops.wino_pack(w)
+    uf4, ud4 = ops.wino43_pack(w)
+    gf = 2 * 9 * Cin * Cout * H * H * B * (16 / 36) / 1e9
+    f2 = timeit(lambda: ops.wino_fwd(x, uf2, b, Cout, relu=True, pool=pooled, keep_full=not pooled))
+    f4 = timeit(lambda: ops.wino43_fwd(x, uf4, b, Cout, relu=True, pool=pooled, keep_full=not pooled))
+    og = torch.randn(B, Cin, H, H, device=dev)
+    if gpooled:
+        gp = torch.randn(B, Cout, H // 2, H // 2, device=dev)
+        idx = torch.randint(0, 4, (B, Cout, H // 2, H // 2), device=dev, dtype=torch.uint8)
+        d2 = timeit(lambda: ops.wino_dgrad_chain(gp, ud2, Cin, pool_idx=idx, out_gate=og))
+        d4 = timeit(lambda: ops.wino43_dgrad_chain(gp, ud4, Cin, pool_idx=idx, out_gate=og))
+    else:
+        gy = torch.randn(B, Cout, H, H, device=dev)
+        d2 = timeit(lambda: ops.wino_dgrad_chain(gy, ud2, Cin, out_gate=og))
+        d4 = timeit(lambda: ops.wino43_dgrad_chain(gy, ud4, Cin, out_gate=og))
+    tot2 += f2 + d2; tot4 += f4 + d4
+    print(f"{name:8s} fwd F2 {f2:7.4f} ms ({gf/f2/157.3:5.3f})  F4 {f4:7.4f} ms (x{f2/f4:4.2f}) | dgrad F2 {d2:7.4f} ms  F4 {d4:7.4f} ms (x{d2/d4:4.2f})", flush=True)
+print("sum: F(2x2) %.3f ms, F(4x4) %.3f ms" % (tot2, tot4))
