@@ -67,6 +67,10 @@ struct st3d_vgg {
     float *wd[16];
     float *uf[16];     // Winograd packs (wino.hip), nullptr where the layer shape is not supported
     float *ud[16];
+    float *u6f[16];    // Winograd F(4x4,3x3) packs (wino43.hip), nullptr where not supported
+    float *u6d[16];
+    int wino43_mink;   // layers with at least this many input channels (K of the GEMM) run F(4x4,3x3) where the shape allows;
+                       // 0 = never (ST3D_WINO43=0); ST3D_WINO43_MINK overrides the measured default
     float *bias[16];
     bool set[16];
     bool use_wino;     // ST3D_CONV=direct forces the direct kernels (A/B runs)
@@ -84,6 +88,8 @@ extern "C" int st3d_vgg_create(st3d_vgg **out) {
     v->fuse_tap0 = !(t0 && t0[0] == '0');
     const char *pg = getenv("ST3D_PREGATE");
     v->pregate = !(pg && pg[0] == '0');
+    const char *w6 = getenv("ST3D_WINO43"), *w6k = getenv("ST3D_WINO43_MINK");
+    v->wino43_mink = (w6 && w6[0] == '0') ? 0 : (w6k ? atoi(w6k) : 128);
     for (int i = 0; i < 16; ++i) {
         const size_t n = st3d_conv3x3_packed_floats(kConvCout[i], kConvCin[i]);
         bool ok = hipMalloc(&v->wf[i], n * sizeof(float)) == hipSuccess && hipMalloc(&v->wd[i], n * sizeof(float)) == hipSuccess &&
@@ -92,6 +98,11 @@ extern "C" int st3d_vgg_create(st3d_vgg **out) {
         if (ok && st3d_wino_supported(kConvCin[i], kConvCout[i], 4, 4) && st3d_wino_supported(kConvCout[i], kConvCin[i], 4, 4)) {
             const size_t nu = st3d_wino_packed_floats(kConvCout[i], kConvCin[i]);
             ok = hipMalloc(&v->uf[i], nu * sizeof(float)) == hipSuccess && hipMalloc(&v->ud[i], nu * sizeof(float)) == hipSuccess;
+        }
+        if (ok && v->use_wino && v->wino43_mink > 0 && kConvCin[i] % 64 == 0 && kConvCout[i] % 64 == 0 &&
+            (kConvCin[i] >= v->wino43_mink || kConvCout[i] >= v->wino43_mink)) {
+            const size_t nu = st3d_wino43_packed_floats(kConvCout[i], kConvCin[i]);
+            ok = hipMalloc(&v->u6f[i], nu * sizeof(float)) == hipSuccess && hipMalloc(&v->u6d[i], nu * sizeof(float)) == hipSuccess;
         }
         if (!ok) {
             st3d::set_error("st3d_vgg_create: hipMalloc failed");
@@ -109,6 +120,7 @@ extern "C" int st3d_vgg_set_conv(st3d_vgg *vgg, int module_idx, const float *w, 
     ST3D_CHECK_ARG(s >= 0);
     ST3D_TRY(st3d_conv3x3_pack(w, kConvCout[s], kConvCin[s], vgg->wf[s], vgg->wd[s], stream));
     if (vgg->uf[s]) ST3D_TRY(st3d_wino_pack(w, kConvCout[s], kConvCin[s], vgg->uf[s], vgg->ud[s], stream));
+    if (vgg->u6f[s]) ST3D_TRY(st3d_wino43_pack(w, kConvCout[s], kConvCin[s], vgg->u6f[s], vgg->u6d[s], stream));
     ST3D_HIP(hipMemcpyAsync(vgg->bias[s], b, kConvCout[s] * sizeof(float), hipMemcpyDeviceToDevice, st3d::as_stream(stream)));
     vgg->set[s] = true;
     return ST3D_OK;
@@ -121,6 +133,8 @@ extern "C" int st3d_vgg_destroy(st3d_vgg *vgg) {
         if (vgg->wd[i]) (void)hipFree(vgg->wd[i]);
         if (vgg->uf[i]) (void)hipFree(vgg->uf[i]);
         if (vgg->ud[i]) (void)hipFree(vgg->ud[i]);
+        if (vgg->u6f[i]) (void)hipFree(vgg->u6f[i]);
+        if (vgg->u6d[i]) (void)hipFree(vgg->u6d[i]);
         if (vgg->bias[i]) (void)hipFree(vgg->bias[i]);
     }
     delete vgg;
@@ -204,7 +218,14 @@ struct Scope {   // HIP-event bracket around one kernel family (only when profil
 };
 
 // F_CONV_*: the Winograd launches; F_CONVX_*: the convs Winograd does not cover (conv1_1, odd shapes, ST3D_CONV=direct)
-enum { F_CONV_FWD = 0, F_CONV_DGRAD = 1, F_POOL = 2, F_GRAM_FWD = 3, F_GRAM_BWD = 4, F_ELEM = 5, F_CONVX_FWD = 6, F_CONVX_DGRAD = 7 };
+// F_CONV43_*: the launches that ran Winograd F(4x4,3x3) (wino43.hip: 2.25 instead of 4 MFMA-multiplies per output)
+enum { F_CONV_FWD = 0, F_CONV_DGRAD = 1, F_POOL = 2, F_GRAM_FWD = 3, F_GRAM_BWD = 4, F_ELEM = 5, F_CONVX_FWD = 6, F_CONVX_DGRAD = 7,
+       F_CONV43_FWD = 8, F_CONV43_DGRAD = 9 };
+
+// F(4x4,3x3) for this GEMM?  K = channels reduced over (Cin forward, Cout for the input gradient), M = channels produced
+bool use_wino43(const st3d_vgg *v, int cs, int K, int M, int H, int W) {
+    return v->use_wino && v->wino43_mink > 0 && v->u6f[cs] && K >= v->wino43_mink && st3d_wino43_supported(K, M, H, W);
+}
 
 // keep_full: also materialise the full-resolution output of convs whose 2x2 pool is fused into
 // their epilogue (needed only when a caller asks for that activation: st3d_plan_forward).
@@ -219,11 +240,16 @@ int forward(st3d_plan *p, const float *imgs, int n, int upto, bool keep_full, hi
                 return ST3D_E_STATE;
             }
             const bool wino = p->vgg->use_wino && p->vgg->uf[cs] && st3d_wino_supported(Cin, kConvCout[cs], H, W);
-            Scope sc(p, wino ? F_CONV_FWD : F_CONVX_FWD, s, m);
+            const bool w43 = wino && use_wino43(p->vgg, cs, Cin, kConvCout[cs], H, W);
+            Scope sc(p, w43 ? F_CONV43_FWD : (wino ? F_CONV_FWD : F_CONVX_FWD), s, m);
             if (wino) {
                 const int pool_m = m + 2;          // conv, relu, pool
                 const int pps = (pool_m <= upto) ? pool_slot(pool_m) : -1;
                 float *yfull = (pps < 0 || keep_full) ? p->act[m] : nullptr;
+                if (w43)
+                    ST3D_TRY(st3d_wino43_fwd(x, p->vgg->u6f[cs], p->vgg->bias[cs], yfull, pps >= 0 ? p->act[pool_m] : nullptr,
+                                             pps >= 0 ? p->pidx[pps] : nullptr, n, Cin, kConvCout[cs], H, W, 1, s));
+                else
                 ST3D_TRY(st3d_wino_fwd(x, p->vgg->uf[cs], p->vgg->bias[cs], yfull, pps >= 0 ? p->act[pool_m] : nullptr,
                                        pps >= 0 ? p->pidx[pps] : nullptr, n, Cin, kConvCout[cs], H, W, 1, s));
                 Cin = kConvCout[cs];
@@ -291,7 +317,14 @@ int dgrad_step(st3d_plan *p, int cs, const float *g, bool g_is_pooled, int pool_
     const int m = kConvIdx[cs];
     const int H = p->H[m], W = p->W[m];
     const bool wino = dgrad_is_wino(p, cs);
-    Scope sc(p, wino ? F_CONV_DGRAD : F_CONVX_DGRAD, s, m);
+    // F(4x4,3x3) takes an already gated gradient only (what the producer-gated chain hands on)
+    const bool w43 = wino && pregated && use_wino43(p->vgg, cs, kConvCout[cs], kConvCin[cs], H, W);
+    Scope sc(p, w43 ? F_CONV43_DGRAD : (wino ? F_CONV_DGRAD : F_CONVX_DGRAD), s, m);
+    if (w43) {
+        ST3D_TRY(st3d_wino43_dgrad_chain(g, g_is_pooled ? p->pidx[pool_of_g] : nullptr, p->vgg->u6d[cs], out_gate, add_target,
+                                         add_coef, dst, n, kConvCin[cs], kConvCout[cs], H, W, s));
+        return ST3D_OK;
+    }
     if (wino && (pregated || out_gate)) {
         const uint8_t *pidx = g_is_pooled ? p->pidx[pool_of_g] : nullptr;
         const float *pooled = (g_is_pooled && !pregated) ? p->act[kPoolIdx[pool_of_g]] : nullptr;

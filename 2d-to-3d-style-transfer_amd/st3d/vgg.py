@@ -275,14 +275,15 @@ class PerceptualPlan:
         call("st3d_plan_profile", self._h, 1 if enable else 0)
 
     def profile_read(self):
-        ms = (ctypes.c_float * 8)()
-        nl = (ctypes.c_int * 8)()
+        ms = (ctypes.c_float * 10)()
+        nl = (ctypes.c_int * 10)()
         call("st3d_plan_profile_read", self._h, ms, nl)
-        names = ("conv_fwd", "conv_dgrad", "pool", "gram_fwd", "gram_bwd", "elementwise", "convx_fwd", "convx_dgrad")
-        return {k: {"ms": ms[i], "launches": nl[i]} for i, k in enumerate(names)}
+        return {k: {"ms": ms[i], "launches": nl[i]} for i, k in enumerate(self.FAMILIES)}
 
 
-    FAMILIES = ("conv_fwd", "conv_dgrad", "pool", "gram_fwd", "gram_bwd", "elementwise", "convx_fwd", "convx_dgrad")
+    # conv_*: Winograd F(2x2,3x3) launches; conv43_*: Winograd F(4x4,3x3); convx_*: direct / vector-ALU kernels
+    FAMILIES = ("conv_fwd", "conv_dgrad", "pool", "gram_fwd", "gram_bwd", "elementwise", "convx_fwd", "convx_dgrad", "conv43_fwd",
+                "conv43_dgrad")
 
     def profile_launches(self):
         """[(family, VGG module index, ms)] for every launch bracket since the last read (profiling on)."""

@@ -384,7 +384,10 @@ def main():
             hw4 = lambda c, d: 4.0 * c * (S // d) ** 2 * Bv          # bytes of a (Bv, c, S/d, S/d) fp32 tensor
             if fam in ("conv_fwd", "conv_dgrad"):
                 alg = conv_alg_flops(module, S, Bv)
-                issued = alg * (16.0 / 36.0)
+                issued = alg * (16.0 / 36.0)            # Winograd F(2x2,3x3): 16 multiplies per 2x2 outputs
+            elif fam in ("conv43_fwd", "conv43_dgrad"):
+                alg = conv_alg_flops(module, S, Bv)
+                issued = alg * (36.0 / 144.0)           # Winograd F(4x4,3x3): 36 multiplies per 4x4 outputs
             elif fam == "convx_dgrad" and module == 0 and ("gram_bwd", 0) not in agg:
                 # csrc/tap0.hip: relu1_1 style gradient + gate + conv1_1 input gradient in one pass, both products on the
                 # matrix pipe (64x64 and 32(27)x64 per pixel); algorithmic bytes: read gradient + activation, write 3 channels
@@ -420,6 +423,7 @@ def main():
             ms = k["ms_per_step"]
             k["ms_per_step"] = round(ms, 4)
             issued, alg, nbytes = k.pop("_issued"), k.pop("_alg"), k.pop("_bytes")
+            k["_issued_flops"], k["_alg_flops"] = issued, alg
             if ms > 0 and issued:
                 k["issued_tflops"] = round(issued / (ms * 1e-3) / 1e12, 2)
                 k["mfma_frac"] = round(issued / (ms * 1e-3) / PEAK_FP32_MFMA, 4)
@@ -485,7 +489,15 @@ def main():
         f_wino_alg = sum(conv_alg_flops(m, S, Bv) for m, *_ in CONVS if m != 0) * 2
         if content_each_step:
             f_wino_alg += sum(conv_alg_flops(m, S, Bv) for m, *_ in CONVS if 0 < m <= 21)
-        f_issued_step = (f_wino_alg * (16.0 / 36.0) if wino else f_wino_alg + 2 * conv_alg_flops(0, S, Bv)) \
+        wfams = ("conv_fwd", "conv_dgrad", "conv43_fwd", "conv43_dgrad")
+        if kernels and any(f in kernels for f in wfams):
+            # what the Winograd launches of a step actually issued: per launch F(2x2,3x3) = 16/36, F(4x4,3x3) = 36/144 of the
+            # direct count, as tagged by the plan's profile (conv_* / conv43_* families)
+            f_conv_issued_measured = sum(kernels[f]["_issued_flops"] for f in wfams if f in kernels)
+        else:
+            f_conv_issued_measured = None
+        f_issued_step = ((f_conv_issued_measured if f_conv_issued_measured is not None else f_wino_alg * (16.0 / 36.0)) if wino
+                         else f_wino_alg + 2 * conv_alg_flops(0, S, Bv)) \
             + sum(gram_fwd_issued_flops(m, S, Bv) + gram_alg_flops(m, S, Bv) for m in STYLE_TAPS)
         if os.environ.get("ST3D_TAP0_FUSED") != "0":
             f_issued_step += 2.0 * 32 * 64 * S * S * Bv        # conv1_1's input gradient as an MFMA product (csrc/tap0.hip)
@@ -513,12 +525,13 @@ def main():
                     "timed region (%.3f ms/step); alg_equiv_tflops prices the same time with the direct-convolution count of "
                     "SURVEY.md 8d (%.1f GF/step)" % (f_issued_step / 1e9, dev_ms / args.steps, f_alg_step / 1e9)}
         roofline = step_roofline
-        if kernels and kernels.get("conv_fwd", {}).get("ms_per_step", 0) > 0 and kernels.get("conv_dgrad", {}).get("ms_per_step", 0) > 0:
-            # the dominant kernel: the Winograd conv launches (forward + input-gradient), priced together
-            kms = kernels["conv_fwd"]["ms_per_step"] + kernels["conv_dgrad"]["ms_per_step"]
-            kn = kernels["conv_fwd"]["launches_per_step"] + kernels["conv_dgrad"]["launches_per_step"]
-            f_conv_alg = f_wino_alg if wino else f_wino_alg
-            f_conv_issued = f_conv_alg * (16.0 / 36.0 if wino else 1.0)
+        if kernels and sum(kernels.get(f, {}).get("ms_per_step", 0) for f in wfams) > 0 and args.approach != "first_b":
+            # the dominant kernel: the Winograd conv launches (forward + input-gradient, both tile sizes), priced together
+            kms = sum(kernels[f]["ms_per_step"] for f in wfams if f in kernels)
+            kn = sum(kernels[f]["launches_per_step"] for f in wfams if f in kernels)
+            f_conv_alg = sum(kernels[f]["_alg_flops"] for f in wfams if f in kernels)
+            f_conv_issued = f_conv_issued_measured if wino else f_conv_alg
+            n43 = sum(kernels[f]["launches_per_step"] for f in ("conv43_fwd", "conv43_dgrad") if f in kernels)
             ktraffic = None
             if traffic and kn == traffic.get("wino_kernel_launches_per_step"):
                 ktraffic = (traffic["wino_fetch_bytes_raw_per_step"] + traffic["wino_write_bytes_per_step"]) / kn
@@ -527,12 +540,14 @@ def main():
                 "unit": "TFLOP/s", "frac": round(f_conv_issued / (kms * 1e-3) / PEAK_FP32_MFMA, 4),
                 "traffic": ktraffic, "traffic_source": tsrc if ktraffic else None,
                 "alg_equiv_tflops": round(f_conv_alg / (kms * 1e-3) / 1e12, 3),
-                "kernel": "wino4_kernel<MODE,EPI> (csrc/wino.hip)" if wino else "conv3x3_kernel (csrc/conv.hip)",
+                "kernel": ("wino43_kernel (csrc/wino43.hip, F(4x4,3x3): %d launches) + wino4_kernel (csrc/wino.hip, F(2x2,3x3): %d launches)"
+                           % (n43, kn - n43)) if wino else "conv3x3_kernel (csrc/conv.hip)",
                 "launches_per_step": kn, "avg_launch_ms": round(kms / kn, 4), "ms_per_step": round(kms, 4),
                 "share_of_step": round(kms / (dev_ms / args.steps), 4),
                 "flops_per_launch_issued": round(f_conv_issued / kn), "flops_per_launch_alg": round(f_conv_alg / kn),
                 "note": "achieved = MFMA flops ISSUED by these launches (Winograd F(2x2,3x3): 16 multiplies per 2x2 outputs = "
-                        "16/36 of the 2*9*Cin*Cout per output pixel of the direct convolutions they replace, forward + "
+                        "16/36, F(4x4,3x3): 36 per 4x4 outputs = 36/144 of the 2*9*Cin*Cout per output pixel of the direct "
+                        "convolutions they replace, forward + "
                         "input-gradient of every VGG conv but conv1_1: %.1f GF issued, %.1f GF algorithmic per step) / their "
                         "HIP-event time on the launch stream over %d steps after the timed region; frac = matrix-pipe "
                         "utilisation.  alg_equiv_tflops = the direct-convolution count over the same time (may exceed the "
@@ -597,6 +612,9 @@ def main():
             res["allreduce_ms_min"] = round(allreduce_ms_min, 4)        # fastest rank
             res["allreduce_bytes"] = int(sum(q.numel() for q in optimizer.params) * 4)
         if kernels:
+            for k in kernels.values():
+                k.pop("_issued_flops", None)
+                k.pop("_alg_flops", None)
             res["kernels"] = kernels
         if layers and args.layers:
             res["layers"] = layers

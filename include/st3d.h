@@ -414,7 +414,7 @@ int st3d_plan_backward(st3d_plan *plan, int n, int upto_module, const float *con
  * read accumulated milliseconds + launch counts; families: 0 conv_fwd (Winograd launches) 1 conv_dgrad (Winograd)
  * 2 pool 3 gram_fwd 4 gram_bwd 5 loss/elementwise 6 convx_fwd (convs Winograd does not cover: conv1_1, odd shapes)
  * 7 convx_dgrad */
-#define ST3D_PROFILE_FAMILIES 8
+#define ST3D_PROFILE_FAMILIES 10
 int st3d_plan_profile(st3d_plan *plan, int enable);
 int st3d_plan_profile_read(st3d_plan *plan, float *ms_out /*host [ST3D_PROFILE_FAMILIES]*/,
                            int *launches_out /*host [ST3D_PROFILE_FAMILIES]*/);

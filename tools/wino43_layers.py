@@ -10,7 +10,7 @@ from st3d import ops
 B = int(os.environ.get("B", "8")); S = int(os.environ.get("S", "512"))
 dev = torch.device("cuda:0")
 # (name, Cin, Cout, divisor, pooled_after, grad_arrives_pooled)
-LAYERS = [("conv2_2", 128, 128, 2, True, True), ("conv3_1", 128, 256, 4, False, False), ("conv3_2", 256, 256, 4, False, False),
+LAYERS = [("conv1_2", 64, 64, 1, True, True), ("conv2_1", 64, 128, 2, False, False), ("conv2_2", 128, 128, 2, True, True), ("conv3_1", 128, 256, 4, False, False), ("conv3_2", 256, 256, 4, False, False),
           ("conv3_4", 256, 256, 4, True, True), ("conv4_1", 256, 512, 8, False, False), ("conv4_2", 512, 512, 8, False, False),
           ("conv4_4", 512, 512, 8, True, True)]
 def timeit(fn, n=10):
