@@ -64,6 +64,10 @@ def build(force=False, jobs=4, verbose=True):
             for k in ("ST3D_WINO_SCHED", "ST3D_WINO_KS", "ST3D_WINO_UDEPTH"):     # stage-loop schedule variants (A/B runs, tools/wino_sched_ab.sh)
                 if os.environ.get(k):
                     flags = flags + ["-D%s=%s" % (k, os.environ[k])]
+        if src == "wino43.hip" and os.environ.get("ST3D_W43_SCHED"):
+            flags = flags + ["-DST3D_W43_SCHED=%s" % os.environ["ST3D_W43_SCHED"]]
+        if src == "wino43.hip" and os.environ.get("ST3D_W43_DIAG_U"):
+            flags = flags + ["-DST3D_W43_DIAG_U"]
         if force or _newer(s, o, hdrs):
             todo.append([HIPCC] + COMMON + flags + ["-c", s, "-o", o])
 

@@ -18,15 +18,18 @@
 //     wino4_kernel has, for 2.25 instead of 4 MFMA-multiplies per output.
 //   * A operands U = G g G^T (fp64 -> fp32, packed per lane: 12 contiguous floats per 4-channel k-step) come straight from
 //     L2 through a buffer descriptor, one k-step ahead; they never touch LDS.
-//   * Staging: 8 channels per stage, 3-deep ring, one barrier per stage.  An item = (channel, 16-byte column strip): six
-//     row loads -> gate (MODE) -> row transform -> six 16-byte LDS stores.  144 items per stage = 2.25 waves, so the four
-//     groups of three waves take turns (stage c: group c & 3): every wave stages once in four stages.
+//   * Staging: 16 channels per stage, 3-deep ring, one barrier per stage.  A half-item = (channel, column pair): six row
+//     loads -> gate (MODE) -> row transform -> six 8-byte LDS stores.  576 half-items per stage on 768 threads: every
+//     wave stages the same amount every stage, interleaved with its MFMAs -- with one workgroup per CU a wave that works
+//     alone behind its MFMAs (staging in turns was tried first) holds up all twelve at the barrier.
 //   * Epilogue: along b in registers (partial over the wave's three b), then per output column j one LDS exchange
 //     [6 a][64 co][16 tiles][2 bh]; a reader owns whole 4x4 output tiles (two per thread of the first 8 waves), so the
 //     2x2 max-pool (+argmax), ReLU, the producer-side gates of the backward chain and 16-byte row stores all happen in
 //     registers, as in wino4_kernel.
 #include <stdlib.h>
 #include <string.h>
+
+#include <type_traits>
 
 #include "common.h"
 
@@ -39,13 +42,16 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int NT6 = 768;                 // 12 waves
 constexpr int T6_ROWS = 4, T6_COLS = 64; // output pixels per workgroup: one row of 16 4x4 tiles
-constexpr int KS6 = 8;                   // input channels per stage (two k-steps of 4)
-constexpr int PITCH6 = 72;               // 18 strips of 4 floats: patch columns x0 - 4 .. x0 + 67
+constexpr int KS6 = 16;                  // input channels per stage (four k-steps of 4): one barrier and one staging turn per 48 MFMAs
+constexpr int NK6 = KS6 / 4;
+constexpr int PITCH6 = 76;               // 18 strips of 4 floats (patch columns x0 - 4 .. x0 + 67) stored from index 1: a tile's six
+                                         // columns 4 tx + 3 .. + 8 then start 16-byte aligned (one 16-byte + one 8-byte LDS read)
 constexpr int STRIPS6 = 18;
-constexpr int ITEMS6 = KS6 * STRIPS6;    // 144 staging items per stage
+constexpr int ITEMS6 = KS6 * STRIPS6;    // 288 staging items per stage: 4.5 waves -> the two groups of six waves take turns
+constexpr int GRP6 = 384;                // threads per staging group
 constexpr int TSTAGE6 = KS6 * 6 * PITCH6;        // floats per ring stage: [ci 8][a 6][72]
 constexpr int EX6 = 6 * 64 * 16 * 2;             // exchange floats per output column: [a 6][co 64][tile 16][bh 2]
-constexpr int SMEM6 = EX6 > 3 * TSTAGE6 ? EX6 : 3 * TSTAGE6;      // 48 KB
+constexpr int SMEM6 = EX6 > 3 * TSTAGE6 ? EX6 : 3 * TSTAGE6;      // 81 KB (dynamic shared memory: above the 64 KB static limit)
 
 struct Wino43Args {
     const float *x;       // MODE 0: (N,Cin,H,W); MODE 3: pooled-resolution gradient (N,Cin,H/2,W/2), already gated
@@ -77,13 +83,11 @@ __device__ __forceinline__ void bt6(float d0, float d1, float d2, float d3, floa
 // EPI 1: MaxPool2d(2,2) (+argmax) fused into the epilogue.  GATE as in wino4_kernel (0 none, 1 output gate, 2 + content term).
 template <int MODE, int EPI, int GATE>
 __global__ __launch_bounds__(NT6, 3) void wino43_kernel(const Wino43Args a) {
-    __shared__ __attribute__((aligned(16))) float smem[SMEM6];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (scalar: every role test below is a scalar branch)
     const int wa = wave >> 1, bh = wave & 1;           // row a of the domain, b half
     const int tx = lane & 15, kq = lane >> 4;           // MFMA n index (tile) / k index (channel within the k-step)
-    const int grp = wave / 3;                           // staging group (takes stage c when (c & 3) == grp)
-    const int e = tid - grp * 192;                      // staging item of this thread within its group's turn
 
     // grid: cout tile fastest, then pixel tiles (x, y), then image
     int bid = blockIdx.x;
@@ -101,23 +105,26 @@ __global__ __launch_bounds__(NT6, 3) void wino43_kernel(const Wino43Args a) {
     const int nstages = a.Cin / KS6;
     const unsigned kOob = 0x80000000u;
 
-    // ---- staging addresses: item = (channel ci, strip l): rows gy = y0 - 1 + r, columns x0 - 4 + 4 l .. + 3
-    const int s_ci = e / STRIPS6, s_l = e - s_ci * STRIPS6;
-    const bool s_on = e >= 0 && e < ITEMS6;
+    // ---- staging: EVERY thread stages one half-item per stage = (channel ci, strip l, column pair h): rows gy = y0 - 1 + r,
+    // columns x0 - 4 + 4 l + 2 h, + 1.  576 half-items on 768 threads: all twelve waves carry the same staging work, so it
+    // sits in the same basic block as their MFMAs (interleaved, no tail behind them) and nobody is late at the barrier.
+    const int s_ci = tid / 36, s_rem = tid - s_ci * 36;
+    const int s_col = 2 * s_rem;                         // = 4 l + 2 h, column offset inside the 72-float strip row
+    const bool s_on = tid < ITEMS6 * 2;
     unsigned voff[6];
     unsigned rowbit[UNPOOL ? 6 : 1];
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
-        const int gy = y0 - 1 + r, gx0 = x0 - 4 + 4 * s_l;
+        const int gy = y0 - 1 + r, gx0 = x0 - 4 + s_col;
         const bool ok = s_on && gy >= 0 && gy < H && gx0 >= 0 && gx0 < W;
-        if (UNPOOL) {
+        if (UNPOOL) {       // one pooled element (and its argmax byte) covers this row's two columns
             voff[r] = ok ? (unsigned)((s_ci * in_plane + (size_t)(gy >> 1) * Wp + (gx0 >> 1)) * 4) : kOob;
             rowbit[r] = (unsigned)(gy & 1) << 1;
         } else {
             voff[r] = ok ? (unsigned)((s_ci * in_plane + (size_t)gy * W + gx0) * 4) : kOob;
         }
     }
-    const int loff = s_on ? (s_ci * 6 * PITCH6 + 4 * s_l) : 0;       // + a * PITCH6 per transformed row
+    const int loff = s_on ? (s_ci * 6 * PITCH6 + s_col + 1) : 0;      // + a * PITCH6 per transformed row (odd index: two 4-byte stores in one ds_write2)
     const unsigned img_bytes = (unsigned)((size_t)a.Cin * in_plane * 4);
     const unsigned stage_bytes = (unsigned)(KS6 * in_plane * 4);
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
@@ -130,60 +137,51 @@ __global__ __launch_bounds__(NT6, 3) void wino43_kernel(const Wino43Args a) {
         const_cast<float *>(a.U + (size_t)ct * nksteps * (12 * 64 * 12)), 0, (unsigned)((size_t)nksteps * 12 * 64 * 12 * 4), 0x00020000);
     const unsigned uvoff = (unsigned)((wave * 64 + lane) * 48);
 
-    f32x4 xv[UNPOOL ? 1 : 6];
-    f32x2 xg[UNPOOL ? 6 : 1];
-    unsigned xi[UNPOOL ? 6 : 1];
-    auto gload = [&](int st) __attribute__((always_inline)) {
+    struct Staged { f32x2 v[UNPOOL ? 1 : 6]; float g[UNPOOL ? 6 : 1]; unsigned i[UNPOOL ? 6 : 1]; };
+    auto gload = [&](int st, Staged &x) __attribute__((always_inline)) {
         const unsigned so = (unsigned)st * stage_bytes;
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
             if (UNPOOL) {
-                xg[r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rx, voff[r], so, 0));
-                xi[r] = __builtin_amdgcn_raw_buffer_load_b16(ridx, voff[r] == kOob ? kOob : voff[r] / 4, so / 4, 0);
+                x.g[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, voff[r], so, 0));
+                x.i[r] = __builtin_amdgcn_raw_buffer_load_b8(ridx, voff[r] == kOob ? kOob : voff[r] / 4, so / 4, 0);
             } else {
-                xv[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff[r], so, 0));
+                x.v[r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rx, voff[r], so, 0));
             }
         }
     };
-    // gate (MODE 3: route the pooled gradient to its argmax position), row-transform, store the six T rows of the strip
-    auto lstore = [&](int buf) __attribute__((always_inline)) {
-        float d[6][4];
+    // gate (MODE 3: route the pooled gradient to its argmax position), row-transform the two columns, store the six T rows
+    auto lstore = [&](int buf, const Staged &x) __attribute__((always_inline)) {
+        f32x2 t[6];
 #pragma unroll
-        for (int r = 0; r < 6; ++r)
+        for (int j2 = 0; j2 < 2; ++j2) {
+            float d[6];
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                if (UNPOOL) {
-                    const unsigned ib = (xi[r] >> (8 * (jj >> 1))) & 0xffu;
-                    d[r][jj] = (ib == (rowbit[r] | (unsigned)(jj & 1))) ? xg[r][jj >> 1] : 0.f;
-                } else {
-                    d[r][jj] = xv[r][jj];
-                }
+            for (int r = 0; r < 6; ++r) {
+                if (UNPOOL) d[r] = ((x.i[r] & 0xffu) == (rowbit[r] | (unsigned)j2)) ? x.g[r] : 0.f;
+                else d[r] = x.v[r][j2];
             }
-        f32x4 t[6];
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
             float t0, t1, t2, t3, t4, t5;
-            bt6(d[0][jj], d[1][jj], d[2][jj], d[3][jj], d[4][jj], d[5][jj], t0, t1, t2, t3, t4, t5);
-            t[0][jj] = t0; t[1][jj] = t1; t[2][jj] = t2; t[3][jj] = t3; t[4][jj] = t4; t[5][jj] = t5;
+            bt6(d[0], d[1], d[2], d[3], d[4], d[5], t0, t1, t2, t3, t4, t5);
+            t[0][j2] = t0; t[1][j2] = t1; t[2][j2] = t2; t[3][j2] = t3; t[4][j2] = t4; t[5][j2] = t5;
         }
+        float *dst = &smem[buf * TSTAGE6 + loff];
         if (s_on) {
-            float *dst = &smem[buf * TSTAGE6 + loff];
 #pragma unroll
-            for (int aa = 0; aa < 6; ++aa) *reinterpret_cast<f32x4 *>(dst + aa * PITCH6) = t[aa];
+            for (int aa = 0; aa < 6; ++aa) { dst[aa * PITCH6] = t[aa][0]; dst[aa * PITCH6 + 1] = t[aa][1]; }
         }
     };
 
     // ---- B operands: this lane's row-a values of (tile tx, channel 4 kk + kq): columns 4 tx + 3 .. 4 tx + 8 of the strip row
     const int tbase = (kq * 6 + wa) * PITCH6 + 4 * tx;
-    struct Trow { float t0; f32x4 m; float t5; };
+    struct Trow { f32x4 m; f32x2 n; };       // t0..t3, t4..t5
     auto tread = [&](int buf, int kk, Trow &o) __attribute__((always_inline)) {
         const float *p = &smem[buf * TSTAGE6 + kk * (4 * 6 * PITCH6) + tbase];
-        o.t0 = p[3];
-        o.m = *reinterpret_cast<const f32x4 *>(p + 4);
-        o.t5 = p[8];
+        o.m = *reinterpret_cast<const f32x4 *>(p + 4);         // columns 4 tx + 3 .. + 6 of the strip row (stored from index 1)
+        o.n = *reinterpret_cast<const f32x2 *>(p + 8);
     };
     auto vcompute = [&](const Trow &o, float v[3]) __attribute__((always_inline)) {
-        const float t0 = o.t0, t1 = o.m[0], t2 = o.m[1], t3 = o.m[2], t4 = o.m[3], t5 = o.t5;
+        const float t0 = o.m[0], t1 = o.m[1], t2 = o.m[2], t3 = o.m[3], t4 = o.n[0], t5 = o.n[1];
         if (bh == 0) {
             const float p = t4 - 4.f * t2, q = t3 - 4.f * t1;
             v[0] = 4.f * t0 + (t4 - 5.f * t2);
@@ -198,7 +196,11 @@ __global__ __launch_bounds__(NT6, 3) void wino43_kernel(const Wino43Args a) {
     };
     struct Uop { f32x4 q[3]; };               // [b 3] -> 4 floats (cout block)
     auto uload = [&](int kstep, Uop &u) __attribute__((always_inline)) {
+#ifdef ST3D_W43_DIAG_U       // diagnostic build: every k-step reads the SAME (cache-resident) filter operands -- wrong results, timing only
+        const unsigned so = (unsigned)(min(kstep, nksteps - 1) & 0) * (unsigned)(12 * 64 * 12 * 4);
+#else
         const unsigned so = (unsigned)min(kstep, nksteps - 1) * (unsigned)(12 * 64 * 12 * 4);
+#endif
 #pragma unroll
         for (int b = 0; b < 3; ++b) u.q[b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, uvoff + 16 * b, so, 0));
     };
@@ -209,49 +211,80 @@ __global__ __launch_bounds__(NT6, 3) void wino43_kernel(const Wino43Args a) {
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) acc[b][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- prologue: stages 0 and 1 staged by groups 0 and 1 at the same time
-    if (grp == 0) { gload(0); lstore(0); }
-    if (grp == 1) { gload(nstages > 1 ? 1 : 0); lstore(1); }
-    Uop ucur, unext;
-    uload(0, ucur);
-    uload(1, unext);
+    // ---- prologue: stages 0 and 1 (both requests in flight together)
+    {
+        Staged x0s, x1s;
+        gload(0, x0s);
+        gload(nstages > 1 ? 1 : 0, x1s);
+        lstore(0, x0s);
+        lstore(1, x1s);
+    }
+    // filter operands THREE k-steps ahead (k-step kk of a stage uses set kk and requests set (kk + 3) & 3): F(4x4,3x3)'s U is
+    // 2.25x the F(2x2,3x3) one (4.7 MB per cout tile at 512 x 512: it streams through the XCD's L2 from the memory-side
+    // cache), and with one workgroup per CU a late operand stalls the whole CU
+    Uop u4[4];
+    uload(0, u4[0]);
+    uload(1, u4[1]);
+    uload(2, u4[2]);
     __syncthreads();
     Trow trow;
     float vcur[3], vnext[3];
     tread(0, 0, trow);
     vcompute(trow, vcur);
 
-    int pb = 0;
-    for (int c = 0; c < nstages; ++c) {
-        const bool mine = grp == (c & 3);
-        const int pb1 = pb == 2 ? 0 : pb + 1, pb2 = pb1 == 2 ? 0 : pb1 + 1;
-        if (mine) gload(min(c + 2, nstages - 1));
+    // One stage = 16 input channels = four k-steps of 12 MFMAs, one barrier.  The loop is unrolled by 3 stages: the ring
+    // position P = c % 3 is a compile-time constant (immediate LDS offsets); k-step kk uses filter-operand set kk and requests
+    // the set of three k-steps ahead.  Staging of stage c + 2: requested at the start of the stage, transformed and stored
+    // under the MFMAs of its last k-step (three k-steps = ~3.5 k cycles in flight; every wave does the same, see above).
+#define W6_MFMAS(u, v)                                                                                            \
+    _Pragma("unroll") for (int b = 0; b < 3; ++b)                                                                 \
+        _Pragma("unroll") for (int cb = 0; cb < 4; ++cb)                                                          \
+            acc[b][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.q[b][cb], v[b], acc[b][cb], 0, 0, 0);
+    Staged xs;
+    auto stage = [&](int c, auto Pc) __attribute__((always_inline)) {
+        constexpr int P = decltype(Pc)::value, pb = P, pb1 = (P + 1) % 3, pb2 = (P + 2) % 3;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            Uop &uc = kk == 0 ? ucur : unext;
-            Uop &un = kk == 0 ? ucur : unext;       // (refilled below once consumed)
-            // the next k-step's row (kk = 1: this stage; kk = 0 of the next stage: its buffer was staged a barrier ago)
-            if (kk == 0) tread(pb, 1, trow); else tread(pb1, 0, trow);
+        for (int kk = 0; kk < NK6; ++kk) {
+            __builtin_amdgcn_sched_barrier(0);
+            // the next k-step's row (the last one prefetches k-step 0 of the NEXT stage: staged a barrier ago)
+            if (kk + 1 < NK6) tread(pb, kk + 1, trow); else tread(pb1, 0, trow);
+            // (B operands ping-pong between vcur / vnext by k-step parity: NK6 is even, so every stage starts on vcur)
+            if (kk & 1) { W6_MFMAS(u4[kk], vnext) } else { W6_MFMAS(u4[kk], vcur) }
+            if (kk == 0) gload(min(c + 2, nstages - 1), xs);
+            uload(NK6 * c + kk + 3, u4[(kk + 3) & 3]);
+            if (kk & 1) vcompute(trow, vcur); else vcompute(trow, vnext);
+            if (kk == NK6 - 1) lstore(pb2, xs);
+            // ST3D_W43_SCHED (compile time): how the k-step's non-MFMA instructions are placed among its 12 MFMAs.
+            //   0: one MFMA, then its share of the others (the wino4_kernel pattern)   1: groups of 4 MFMAs
+            //   2: the 12 MFMAs as one burst, everything else behind it               3: compiler's own order
+#ifndef ST3D_W43_SCHED
+#define ST3D_W43_SCHED 3
+#endif
+            constexpr int MG = ST3D_W43_SCHED == 0 ? 1 : (ST3D_W43_SCHED == 1 ? 4 : 12);
+            if (ST3D_W43_SCHED != 3) {
 #pragma unroll
-            for (int b = 0; b < 3; ++b)
-#pragma unroll
-                for (int cb = 0; cb < 4; ++cb)
-                    acc[b][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(uc.q[b][cb], vcur[b], acc[b][cb], 0, 0, 0);
-            uload(2 * c + kk + 2, un);
-            vcompute(trow, vnext);
-#pragma unroll
-            for (int b = 0; b < 3; ++b) vcur[b] = vnext[b];
-#pragma unroll
-            for (int i_ = 0; i_ < 12; ++i_) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x126, 1, 0);      // one VALU / VMEM read / DS read per MFMA
+                for (int i_ = 0; i_ < 12 / MG; ++i_) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, MG, 0);
+                    if (kk == 0) __builtin_amdgcn_sched_group_barrier(0x120, MG, 0);       // the stage's loads + LDS reads
+                    else if (kk == NK6 - 1) {
+                        __builtin_amdgcn_sched_group_barrier(0x002, 3 * MG, 0);            // gate + row transform + column transform
+                        __builtin_amdgcn_sched_group_barrier(0x320, MG, 0);                // LDS reads / writes, filter loads
+                    } else __builtin_amdgcn_sched_group_barrier(0x126, MG, 0);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (mine) lstore(pb2);
         __syncthreads();
-        pb = pb1;
+    };
+    int c = 0;
+    for (; c + 3 <= nstages; c += 3) {
+        stage(c, std::integral_constant<int, 0>{});
+        stage(c + 1, std::integral_constant<int, 1>{});
+        stage(c + 2, std::integral_constant<int, 2>{});
     }
+    if (c < nstages) stage(c, std::integral_constant<int, 0>{});
+    if (c + 1 < nstages) stage(c + 1, std::integral_constant<int, 1>{});
+#undef W6_MFMAS
 
     // ---- epilogue.  Along b (this wave's three b): z_j = sum_b A^T[j][b] m_b, A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
     //   bh 0 (b 0 1 2): z0 = m0 + s, z1 = z3 = d, z2 = s            with s = m1 + m2, d = m1 - m2
@@ -414,16 +447,24 @@ int launch_wino43(Wino43Args a, hipStream_t s) {
     a.tiles_y = a.H / T6_ROWS;
     a.n_ct = a.Cout / 64;
     const long blocks = (long)a.n_ct * a.tiles_x * a.tiles_y * a.N;
+    constexpr size_t kSmem = (size_t)SMEM6 * sizeof(float);       // 81 KB of dynamic LDS: opt in once per instantiation
+    auto go = [&](auto kernel) -> int {
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmem);
+        if (attr != hipSuccess) { st3d::set_error("wino43: hipFuncSetAttribute(MaxDynamicSharedMemorySize): %s", hipGetErrorString(attr)); return ST3D_E_HIP; }
+        kernel<<<(unsigned)blocks, NT6, kSmem, s>>>(a);
+        ST3D_LAUNCH_CHECK();
+        return ST3D_OK;
+    };
     if (a.yp) {
         if (MODE != 0 || a.gate) { st3d::set_error("wino43: the fused pool belongs to the plain forward"); return ST3D_E_INVALID; }
-        wino43_kernel<0, 1, 0><<<(unsigned)blocks, NT6, 0, s>>>(a);
-    } else if (a.gate && a.addt) {
+        return go(wino43_kernel<0, 1, 0>);
+    }
+    if (a.gate && a.addt) {
         if (MODE != 0) { st3d::set_error("wino43: the content-target term rides on ungated input (MODE 0) only"); return ST3D_E_INVALID; }
-        wino43_kernel<0, 0, 2><<<(unsigned)blocks, NT6, 0, s>>>(a);
-    } else if (a.gate) wino43_kernel<MODE, 0, 1><<<(unsigned)blocks, NT6, 0, s>>>(a);
-    else wino43_kernel<MODE, 0, 0><<<(unsigned)blocks, NT6, 0, s>>>(a);
-    ST3D_LAUNCH_CHECK();
-    return ST3D_OK;
+        return go(wino43_kernel<0, 0, 2>);
+    }
+    if (a.gate) return go(wino43_kernel<MODE, 0, 1>);
+    return go(wino43_kernel<MODE, 0, 0>);
 }
 
 }  // namespace
