@@ -143,6 +143,8 @@ __global__ __launch_bounds__(NT6, 3) void wino43_kernel(const Wino43Args a) {
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
             if (UNPOOL) {
+                // y0 % 4 == 0: patch rows (1, 2) and (3, 4) are the two halves of ONE pooled row each -- four loads, not six
+                if (r == 2 || r == 4) { x.g[r] = x.g[r - 1]; x.i[r] = x.i[r - 1]; continue; }
                 x.g[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, voff[r], so, 0));
                 x.i[r] = __builtin_amdgcn_raw_buffer_load_b8(ridx, voff[r] == kOob ? kOob : voff[r] / 4, so / 4, 0);
             } else {
@@ -294,6 +296,29 @@ __global__ __launch_bounds__(NT6, 3) void wino43_kernel(const Wino43Args a) {
     constexpr int NIT = 2;                         // 4x4 output tiles per reader thread (waves 0..7: 512 threads x 2 = 64 co x 16 tiles)
     const bool reader = tid < 512;
     float yt[NIT][4][4];                           // [item][row i][col j]
+    // the readers' bias and the consumer's ReLU gate (GATE >= 1) are requested NOW: they arrive under the four exchange
+    // passes instead of in front of the stores (one workgroup per CU: an exposed HBM round trip idles the whole CU)
+    const unsigned out_bytes = (unsigned)((size_t)a.Cout * HW * 4);
+    unsigned vo_it[NIT];
+    float bias_it[NIT];
+    f32x4 gq[GATE >= 1 ? NIT : 1][4];
+    if (reader) {
+        __amdgpu_buffer_rsrc_t rg = rx;
+        if (GATE >= 1) rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.gate + (size_t)n * a.Cout * HW), 0, out_bytes, 0x00020000);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int q = tid + 512 * it, col = q >> 4, tl = q & 15;
+            const int ox = x0 + 4 * tl;
+            const bool inb = y0 < H && ox < W;           // H % 4 == 0, W % 64 == 0: always (kept for the descriptor sentinel)
+            vo_it[it] = inb ? (unsigned)((((size_t)co0 + col) * HW + (size_t)y0 * W + ox) * 4) : kOob;
+            bias_it[it] = a.bias ? a.bias[co0 + col] : 0.f;
+            if (GATE >= 1 && it == 0) {       // (the second item's gate is requested behind the passes: 16 more live registers spill)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    gq[it][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, vo_it[it], (unsigned)(i * W * 4), 0));
+            }
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -329,10 +354,16 @@ __global__ __launch_bounds__(NT6, 3) void wino43_kernel(const Wino43Args a) {
     }
     if (!reader) return;
 
-    const unsigned out_bytes = (unsigned)((size_t)a.Cout * HW * 4);
-    __amdgpu_buffer_rsrc_t ry = rx, ryp = rx, ryi = rx, rg = rx, rt = rx;
+    __amdgpu_buffer_rsrc_t ry = rx, ryp = rx, ryi = rx, rt = rx;
+    if (GATE >= 1) {
+        const __amdgpu_buffer_rsrc_t rg2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.gate + (size_t)n * a.Cout * HW), 0, out_bytes, 0x00020000);
+#pragma unroll
+        for (int it = 1; it < NIT; ++it)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                gq[it][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg2, vo_it[it], (unsigned)(i * W * 4), 0));
+    }
     if (a.y) ry = __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)n * a.Cout * HW, 0, out_bytes, 0x00020000);
-    if (GATE >= 1) rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.gate + (size_t)n * a.Cout * HW), 0, out_bytes, 0x00020000);
     if (GATE == 2) rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.addt + (size_t)n * a.Cout * HW), 0, out_bytes, 0x00020000);
     const size_t HpWp = (size_t)Hp * Wp;
     if (EPI == 1) {
@@ -344,9 +375,9 @@ __global__ __launch_bounds__(NT6, 3) void wino43_kernel(const Wino43Args a) {
     for (int it = 0; it < NIT; ++it) {
         const int q = tid + 512 * it, col = q >> 4, tl = q & 15;
         const int oy = y0, ox = x0 + 4 * tl;
-        const bool inb = oy < H && ox < W;               // H % 4 == 0, W % 64 == 0: always (kept for the descriptor sentinel)
-        const float bsum = a.bias ? a.bias[co0 + col] : 0.f;
-        const unsigned vo = inb ? (unsigned)((((size_t)co0 + col) * HW + (size_t)oy * W + ox) * 4) : kOob;
+        const unsigned vo = vo_it[it];
+        const bool inb = vo != kOob;
+        const float bsum = bias_it[it];
         f32x4 rowv[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -357,7 +388,7 @@ __global__ __launch_bounds__(NT6, 3) void wino43_kernel(const Wino43Args a) {
                 rowv[i][j] = v;
             }
             if (GATE >= 1) {
-                const f32x4 g = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, vo, (unsigned)(i * W * 4), 0));
+                const f32x4 g = gq[it][i];
                 if (GATE == 2) {
                     const f32x4 tg = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rt, vo, (unsigned)(i * W * 4), 0));
 #pragma unroll
