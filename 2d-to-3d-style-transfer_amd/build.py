@@ -66,8 +66,8 @@ def build(force=False, jobs=4, verbose=True):
                     flags = flags + ["-D%s=%s" % (k, os.environ[k])]
         if src == "wino43.hip" and os.environ.get("ST3D_W43_SCHED"):
             flags = flags + ["-DST3D_W43_SCHED=%s" % os.environ["ST3D_W43_SCHED"]]
-        if src == "wino43.hip" and os.environ.get("ST3D_W43_DIAG_U"):
-            flags = flags + ["-DST3D_W43_DIAG_U"]
+        if src == "wino43.hip" and os.environ.get("ST3D_W43_DIAG"):      # timing-only diagnostic builds (wrong results), see wino43.hip
+            flags = flags + ["-DST3D_W43_DIAG=%s" % os.environ["ST3D_W43_DIAG"]]
         if force or _newer(s, o, hdrs):
             todo.append([HIPCC] + COMMON + flags + ["-c", s, "-o", o])
 

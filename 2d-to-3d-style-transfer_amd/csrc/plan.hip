@@ -89,7 +89,7 @@ extern "C" int st3d_vgg_create(st3d_vgg **out) {
     const char *pg = getenv("ST3D_PREGATE");
     v->pregate = !(pg && pg[0] == '0');
     const char *w6 = getenv("ST3D_WINO43"), *w6k = getenv("ST3D_WINO43_MINK");
-    v->wino43_mink = (w6 && w6[0] == '0') ? 0 : (w6k ? atoi(w6k) : 128);
+    v->wino43_mink = (w6 && w6[0] == '0') ? 0 : (w6k ? atoi(w6k) : 64);
     for (int i = 0; i < 16; ++i) {
         const size_t n = st3d_conv3x3_packed_floats(kConvCout[i], kConvCin[i]);
         bool ok = hipMalloc(&v->wf[i], n * sizeof(float)) == hipSuccess && hipMalloc(&v->wd[i], n * sizeof(float)) == hipSuccess &&

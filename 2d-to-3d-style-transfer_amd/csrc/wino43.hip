@@ -2,8 +2,8 @@
 // (round 3): 36 multiplies per 4x4 output tile = 2.25 per output pixel, against 4 for the F(2x2,3x3) of wino.hip and 9
 // for the direct convolution.  Still fp32 products and fp32 accumulation; the larger transform constants cost about one
 // decimal digit (measured <= 1.3e-5 of the output scale at K = 512 against an fp64 convolution; F(2x2,3x3): 1e-6), inside
-// the 3e-5 the Winograd kernels are tested to.  Used for the deep layers (Cin >= 128 at W % 64 == 0), where the K loop
-// dominates; the short-K layers stay on wino4_kernel.
+// the 3e-5 the Winograd kernels are tested to.  Used for every layer with Cin >= 64 and W % 64 == 0; narrower maps (conv5_1
+// at 512 x 512) stay on wino4_kernel.
 //
 //   Y = A^T [ sum_ci (G g G^T) (.) (B^T d B) ] A       per (cout, 4x4 tile), 6x6 Winograd domain xi = (a, b)
 //
@@ -17,11 +17,15 @@
 //     three b (6-7 VALU).  That is the same ~1 vector-ALU instruction per 64 MFMA cycles in the waves' loop as
 //     wino4_kernel has, for 2.25 instead of 4 MFMA-multiplies per output.
 //   * A operands U = G g G^T (fp64 -> fp32, packed per lane: 12 contiguous floats per 4-channel k-step) come straight from
-//     L2 through a buffer descriptor, one k-step ahead; they never touch LDS.
+//     L2 through a buffer descriptor, three k-steps ahead; they never touch LDS.
 //   * Staging: 16 channels per stage, 3-deep ring, one barrier per stage.  A half-item = (channel, column pair): six row
-//     loads -> gate (MODE) -> row transform -> six 8-byte LDS stores.  576 half-items per stage on 768 threads: every
-//     wave stages the same amount every stage, interleaved with its MFMAs -- with one workgroup per CU a wave that works
-//     alone behind its MFMAs (staging in turns was tried first) holds up all twelve at the barrier.
+//     loads -> gate (MODE) -> row transform of both columns in packed fp32 math -> six 8-byte LDS stores.  576 half-items
+//     per stage on 768 threads: every wave stages the same amount every stage, interleaved with its MFMAs -- with one
+//     workgroup per CU a wave that works alone behind its MFMAs (staging in turns was tried first) holds up all twelve at
+//     the barrier.
+//   * PERSISTENT workgroups, one per CU: workgroup (cout tile, slot) walks the pixel tiles slot, slot + nslots, ...; the
+//     stream of stages runs on from one tile into the next (the ring holds the next tile's first two stages when a tile's
+//     last MFMA issues), the exchange region is separate from the ring, and only the epilogue stands between two tiles.
 //   * Epilogue: along b in registers (partial over the wave's three b), then per output column j one LDS exchange
 //     [6 a][64 co][16 tiles][2 bh]; a reader owns whole 4x4 output tiles (two per thread of the first 8 waves), so the
 //     2x2 max-pool (+argmax), ReLU, the producer-side gates of the backward chain and 16-byte row stores all happen in
@@ -47,11 +51,11 @@ constexpr int NK6 = KS6 / 4;
 constexpr int PITCH6 = 76;               // 18 strips of 4 floats (patch columns x0 - 4 .. x0 + 67) stored from index 1: a tile's six
                                          // columns 4 tx + 3 .. + 8 then start 16-byte aligned (one 16-byte + one 8-byte LDS read)
 constexpr int STRIPS6 = 18;
-constexpr int ITEMS6 = KS6 * STRIPS6;    // 288 staging items per stage: 4.5 waves -> the two groups of six waves take turns
-constexpr int GRP6 = 384;                // threads per staging group
+constexpr int ITEMS6 = KS6 * STRIPS6;    // 288 staging items (channel, strip) per stage = 576 half-items on 768 threads
 constexpr int TSTAGE6 = KS6 * 6 * PITCH6;        // floats per ring stage: [ci 8][a 6][72]
 constexpr int EX6 = 6 * 64 * 16 * 2;             // exchange floats per output column: [a 6][co 64][tile 16][bh 2]
-constexpr int SMEM6 = EX6 > 3 * TSTAGE6 ? EX6 : 3 * TSTAGE6;      // 81 KB (dynamic shared memory: above the 64 KB static limit)
+constexpr int SMEM6 = 3 * TSTAGE6 + EX6;         // 134 KB (dynamic shared memory): the ring AND the exchange region -- a persistent
+                                                 // workgroup keeps staging its next tile while the finished one is written out
 
 struct Wino43Args {
     const float *x;       // MODE 0: (N,Cin,H,W); MODE 3: pooled-resolution gradient (N,Cin,H/2,W/2), already gated
@@ -65,22 +69,31 @@ struct Wino43Args {
     const float *gate;    // (N,Cout,H,W) or nullptr: outputs are zeroed where gate <= 0 (the consumer's ReLU gate, see wino.hip)
     const float *addt;    // with gate: outputs become gate > 0 ? y + addc * (gate - addt) : 0
     float addc;
+    unsigned magic_x, magic_y;      // floor(2^32 / tiles_x) + 1, likewise tiles_y: pix / tiles_x = umulhi(pix, magic_x) for pix * tiles_x < 2^32 (tiles_x >= 2)
 };
 
 // T_a = sum_r B^T[a][r] d[r] for a = 0..5 (and, applied to t0..t5, the column half V_b = sum_c B^T[b][c] t[c])
 //   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
-__device__ __forceinline__ void bt6(float d0, float d1, float d2, float d3, float d4, float d5, float &t0, float &t1, float &t2,
-                                    float &t3, float &t4, float &t5) {
-    const float p = d4 - 4.f * d2, q = d3 - 4.f * d1;
+// (T = f32x2: two patch columns at once in packed fp32 math -- v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32: 14 instructions
+//  for both columns; every non-MFMA instruction of the stage loop is exposed next to the fp32 MFMAs)
+template <typename T>
+__device__ __forceinline__ void bt6(T d0, T d1, T d2, T d3, T d4, T d5, T &t0, T &t1, T &t2, T &t3, T &t4, T &t5) {
+    const T p = d4 - 4.f * d2, q = d3 - 4.f * d1;
     t1 = p + q; t2 = p - q;
     t0 = 4.f * d0 + (d4 - 5.f * d2);
-    const float r = d4 - d2, s = 2.f * (d3 - d1);
+    const T r = d4 - d2, s = 2.f * (d3 - d1);
     t3 = r + s; t4 = r - s;
     t5 = 4.f * d1 + (d5 - 5.f * d3);
 }
 
 // MODE 0: plain input.  MODE 3: input = 2x2 max-unpool of a pooled-resolution gradient (routing by the argmax bytes).
 // EPI 1: MaxPool2d(2,2) (+argmax) fused into the epilogue.  GATE as in wino4_kernel (0 none, 1 output gate, 2 + content term).
+#if defined(ST3D_W43_DIAG) && ST3D_W43_DIAG == 5           // diagnostic build: gate reads out of range, stores in place
+#define W43_GATE_VO(v) (a.N >= 0 ? kOob : (v))
+#else
+#define W43_GATE_VO(v) (v)
+#endif
+
 template <int MODE, int EPI, int GATE>
 __global__ __launch_bounds__(NT6, 3) void wino43_kernel(const Wino43Args a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -89,14 +102,22 @@ __global__ __launch_bounds__(NT6, 3) void wino43_kernel(const Wino43Args a) {
     const int wa = wave >> 1, bh = wave & 1;           // row a of the domain, b half
     const int tx = lane & 15, kq = lane >> 4;           // MFMA n index (tile) / k index (channel within the k-step)
 
-    // grid: cout tile fastest, then pixel tiles (x, y), then image
-    int bid = blockIdx.x;
-    const int ct = bid % a.n_ct; bid /= a.n_ct;
-    const int tile_x = bid % a.tiles_x; bid /= a.tiles_x;
-    const int tile_y = bid % a.tiles_y;
-    const int n = bid / a.tiles_y;
-    const int x0 = tile_x * T6_COLS, y0 = tile_y * T6_ROWS;
+    // PERSISTENT workgroups (one per CU): workgroup (ct, slot) walks the pixel tiles slot, slot + nslots, ... of ONE cout tile,
+    // so its filter operands are the same 36 x 64 x K slab for every tile and the stream of stages simply continues from one
+    // tile into the next: the ring already holds the next tile's first two stages when a tile's last MFMA issues, the
+    // operand requests wrap around, and only the output exchange stands between two tiles (no prologue, no relaunch).
+    const int ct = blockIdx.x % a.n_ct, slot = blockIdx.x / a.n_ct, nslots = gridDim.x / a.n_ct;
+    const int npix = a.tiles_x * a.tiles_y * a.N;
     const int co0 = ct * 64;
+    int n = 0, x0 = 0, y0 = 0;                 // the tile whose patch columns are being STAGED (runs two stages ahead)
+    auto decode = [&](int pix, int &tn, int &ty0, int &tx0) __attribute__((always_inline)) {
+        // (scalar multiply-high by the host's reciprocals: a runtime integer division costs ~30 vector instructions, and every
+        //  instruction between two tiles' MFMAs is exposed)
+        const int r2 = a.tiles_x == 1 ? pix : (int)__umulhi((unsigned)pix, a.magic_x);
+        const int txi = pix - r2 * a.tiles_x;
+        tn = a.tiles_y == 1 ? r2 : (int)__umulhi((unsigned)r2, a.magic_y);
+        tx0 = txi * T6_COLS; ty0 = (r2 - tn * a.tiles_y) * T6_ROWS;
+    };
     const int H = a.H, W = a.W;
     const size_t HW = (size_t)H * W;
     const int Hp = H >> 1, Wp = W >> 1;
@@ -114,24 +135,33 @@ __global__ __launch_bounds__(NT6, 3) void wino43_kernel(const Wino43Args a) {
     unsigned voff[6];
     unsigned rowbit[UNPOOL ? 6 : 1];
 #pragma unroll
-    for (int r = 0; r < 6; ++r) {
-        const int gy = y0 - 1 + r, gx0 = x0 - 4 + s_col;
-        const bool ok = s_on && gy >= 0 && gy < H && gx0 >= 0 && gx0 < W;
-        if (UNPOOL) {       // one pooled element (and its argmax byte) covers this row's two columns
-            voff[r] = ok ? (unsigned)((s_ci * in_plane + (size_t)(gy >> 1) * Wp + (gx0 >> 1)) * 4) : kOob;
-            rowbit[r] = (unsigned)(gy & 1) << 1;
-        } else {
-            voff[r] = ok ? (unsigned)((s_ci * in_plane + (size_t)gy * W + gx0) * 4) : kOob;
-        }
-    }
-    const int loff = s_on ? (s_ci * 6 * PITCH6 + s_col + 1) : 0;      // + a * PITCH6 per transformed row (odd index: two 4-byte stores in one ds_write2)
+    for (int r = 0; r < 6; ++r)
+        if (UNPOOL) rowbit[r] = (unsigned)((r + 1) & 1) << 1;        // gy = y0 - 1 + r with y0 % 4 == 0: odd for even r
     const unsigned img_bytes = (unsigned)((size_t)a.Cin * in_plane * 4);
+    __amdgpu_buffer_rsrc_t rx, ridx;
+    // addresses of the staged tile `pix` (>= npix: past this workgroup's last tile -- everything out of range, loads return 0)
+    auto stage_tile = [&](int pix) __attribute__((always_inline)) {
+        const bool live = pix < npix;
+        decode(live ? pix : 0, n, y0, x0);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const int gy = y0 - 1 + r, gx0 = x0 - 4 + s_col;
+            const bool ok = live && s_on && gy >= 0 && gy < H && gx0 >= 0 && gx0 < W;
+            if (UNPOOL) voff[r] = ok ? (unsigned)((s_ci * in_plane + (size_t)(gy >> 1) * Wp + (gx0 >> 1)) * 4) : kOob;   // one pooled element covers the row's two columns
+            else voff[r] = ok ? (unsigned)((s_ci * in_plane + (size_t)gy * W + gx0) * 4) : kOob;
+        }
+        rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x + (size_t)n * a.Cin * in_plane), 0, img_bytes, 0x00020000);
+        ridx = rx;
+        if (UNPOOL)
+            ridx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.idx + (size_t)n * a.Cin * in_plane), 0, img_bytes / 4, 0x00020000);
+    };
+    int spix = slot;                           // pixel tile being staged
+    stage_tile(spix);
+#if defined(ST3D_W43_DIAG) && ST3D_W43_DIAG == 10       // 10: staging loads out of range (issued, no memory traffic)
+    if (a.N >= 0) spix = npix;
+#endif
+    const int loff = s_on ? (s_ci * 6 * PITCH6 + s_col + 1) : 0;      // + a * PITCH6 per transformed row (odd index: two 4-byte stores in one ds_write2)
     const unsigned stage_bytes = (unsigned)(KS6 * in_plane * 4);
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(a.x + (size_t)n * a.Cin * in_plane), 0, img_bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t ridx = rx;
-    if (UNPOOL)
-        ridx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.idx + (size_t)n * a.Cin * in_plane), 0, img_bytes / 4, 0x00020000);
     const int nksteps = a.Cin / 4;
     const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(a.U + (size_t)ct * nksteps * (12 * 64 * 12)), 0, (unsigned)((size_t)nksteps * 12 * 64 * 12 * 4), 0x00020000);
@@ -154,19 +184,17 @@ __global__ __launch_bounds__(NT6, 3) void wino43_kernel(const Wino43Args a) {
     };
     // gate (MODE 3: route the pooled gradient to its argmax position), row-transform the two columns, store the six T rows
     auto lstore = [&](int buf, const Staged &x) __attribute__((always_inline)) {
-        f32x2 t[6];
+        f32x2 t[6], d[6];
 #pragma unroll
-        for (int j2 = 0; j2 < 2; ++j2) {
-            float d[6];
+        for (int r = 0; r < 6; ++r) {
+            if (UNPOOL) {
 #pragma unroll
-            for (int r = 0; r < 6; ++r) {
-                if (UNPOOL) d[r] = ((x.i[r] & 0xffu) == (rowbit[r] | (unsigned)j2)) ? x.g[r] : 0.f;
-                else d[r] = x.v[r][j2];
+                for (int j2 = 0; j2 < 2; ++j2) d[r][j2] = ((x.i[r] & 0xffu) == (rowbit[r] | (unsigned)j2)) ? x.g[r] : 0.f;
+            } else {
+                d[r] = x.v[r];
             }
-            float t0, t1, t2, t3, t4, t5;
-            bt6(d[0], d[1], d[2], d[3], d[4], d[5], t0, t1, t2, t3, t4, t5);
-            t[0][j2] = t0; t[1][j2] = t1; t[2][j2] = t2; t[3][j2] = t3; t[4][j2] = t4; t[5][j2] = t5;
         }
+        bt6<f32x2>(d[0], d[1], d[2], d[3], d[4], d[5], t[0], t[1], t[2], t[3], t[4], t[5]);
         float *dst = &smem[buf * TSTAGE6 + loff];
         if (s_on) {
 #pragma unroll
@@ -198,8 +226,10 @@ __global__ __launch_bounds__(NT6, 3) void wino43_kernel(const Wino43Args a) {
     };
     struct Uop { f32x4 q[3]; };               // [b 3] -> 4 floats (cout block)
     auto uload = [&](int kstep, Uop &u) __attribute__((always_inline)) {
-#ifdef ST3D_W43_DIAG_U       // diagnostic build: every k-step reads the SAME (cache-resident) filter operands -- wrong results, timing only
-        const unsigned so = (unsigned)(min(kstep, nksteps - 1) & 0) * (unsigned)(12 * 64 * 12 * 4);
+        // (a tile's last three requests run past its slab: clamped and never used -- the next tile's first three sets are
+        //  requested from the epilogue, where they need no registers across the exchange passes)
+#if defined(ST3D_W43_DIAG) && ST3D_W43_DIAG == 1       // diagnostic build: every k-step reads the SAME (cache-resident) filter operands -- wrong results, timing only
+        const unsigned so = 0u;
 #else
         const unsigned so = (unsigned)min(kstep, nksteps - 1) * (unsigned)(12 * 64 * 12 * 4);
 #endif
@@ -213,11 +243,19 @@ __global__ __launch_bounds__(NT6, 3) void wino43_kernel(const Wino43Args a) {
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) acc[b][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- prologue: stages 0 and 1 (both requests in flight together)
+    // ---- staging.  A CU's vector loads come back in issue order ACROSS its waves: a patch row that comes from HBM holds up
+    // every filter operand requested after it, by any wave.  Measured on the nine config-2 layers (tools/w43_ab_run.sh, sum of
+    // forward + input gradient): all twelve waves request in k-step 0 BEHIND that k-step's operand request 6.75 ms; in
+    // front of it 6.95; the three waves of a SIMD in different k-steps 7.3 (three hold-ups per stage instead of one); the
+    // request a k-step earlier / the store a stage later through a ring of four 6.85 - 6.95; every request at the head of its
+    // k-step instead of behind the MFMAs 7.08.  With the loads out of range (no memory traffic) the sum is 6.1, with no
+    // staging at all 5.8: the round trip of the patch rows is worth 10 % (20 % at conv1_2, whose input comes from HBM).
+    Staged xs;
+    // ---- prologue (once per workgroup): stages 0 and 1 of its first tile, both requests in flight together
     {
         Staged x0s, x1s;
         gload(0, x0s);
-        gload(nstages > 1 ? 1 : 0, x1s);
+        gload(1, x1s);
         lstore(0, x0s);
         lstore(1, x1s);
     }
@@ -234,199 +272,235 @@ __global__ __launch_bounds__(NT6, 3) void wino43_kernel(const Wino43Args a) {
     tread(0, 0, trow);
     vcompute(trow, vcur);
 
-    // One stage = 16 input channels = four k-steps of 12 MFMAs, one barrier.  The loop is unrolled by 3 stages: the ring
-    // position P = c % 3 is a compile-time constant (immediate LDS offsets); k-step kk uses filter-operand set kk and requests
-    // the set of three k-steps ahead.  Staging of stage c + 2: requested at the start of the stage, transformed and stored
-    // under the MFMAs of its last k-step (three k-steps = ~3.5 k cycles in flight; every wave does the same, see above).
+    // One stage = 16 input channels = four k-steps of 12 MFMAs, one barrier; k-step kk uses filter-operand set kk and
+    // requests the set of three k-steps ahead.  pb = ring position of the stage being computed, sc = the stage (of the
+    // staged tile) requested in k-step 0 and stored, row-transformed, in k-step 3.
 #define W6_MFMAS(u, v)                                                                                            \
     _Pragma("unroll") for (int b = 0; b < 3; ++b)                                                                 \
         _Pragma("unroll") for (int cb = 0; cb < 4; ++cb)                                                          \
             acc[b][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.q[b][cb], v[b], acc[b][cb], 0, 0, 0);
-    Staged xs;
-    auto stage = [&](int c, auto Pc) __attribute__((always_inline)) {
-        constexpr int P = decltype(Pc)::value, pb = P, pb1 = (P + 1) % 3, pb2 = (P + 2) % 3;
+#if defined(ST3D_W43_DIAG) && ST3D_W43_DIAG == 6        // 6: no staging in the loop
+#define W6_GLOAD(sc) ((void)0)
+#define W6_LSTORE(buf) ((void)0)
+#elif defined(ST3D_W43_DIAG) && ST3D_W43_DIAG == 11     // 11: staging loads waited for, no transform / LDS stores
+#define W6_GLOAD(sc) gload(sc, xs)
+#define W6_LSTORE(buf) do { for (int r = 0; r < (UNPOOL ? 1 : 6); ++r) asm volatile("" :: "v"(xs.v[r])); if (UNPOOL) for (int r = 0; r < 6; ++r) asm volatile("" :: "v"(xs.g[r]), "v"(xs.i[r])); } while (0)
+#else
+#define W6_GLOAD(sc) gload(sc, xs)
+#define W6_LSTORE(buf) lstore(buf, xs)
+#endif
+    auto stage = [&](int c, int sc, int pb) __attribute__((always_inline)) {
+        const int pb1 = pb == 2 ? 0 : pb + 1, pb2 = pb1 == 2 ? 0 : pb1 + 1;
 #pragma unroll
         for (int kk = 0; kk < NK6; ++kk) {
             __builtin_amdgcn_sched_barrier(0);
             // the next k-step's row (the last one prefetches k-step 0 of the NEXT stage: staged a barrier ago)
+#if !(defined(ST3D_W43_DIAG) && ST3D_W43_DIAG == 9)        // 9: no B-operand reads / column transform in the loop
             if (kk + 1 < NK6) tread(pb, kk + 1, trow); else tread(pb1, 0, trow);
+#endif
             // (B operands ping-pong between vcur / vnext by k-step parity: NK6 is even, so every stage starts on vcur)
             if (kk & 1) { W6_MFMAS(u4[kk], vnext) } else { W6_MFMAS(u4[kk], vcur) }
-            if (kk == 0) gload(min(c + 2, nstages - 1), xs);
+#if !(defined(ST3D_W43_DIAG) && ST3D_W43_DIAG == 7)        // 7: no filter-operand loads in the loop
             uload(NK6 * c + kk + 3, u4[(kk + 3) & 3]);
-            if (kk & 1) vcompute(trow, vcur); else vcompute(trow, vnext);
-            if (kk == NK6 - 1) lstore(pb2, xs);
-            // ST3D_W43_SCHED (compile time): how the k-step's non-MFMA instructions are placed among its 12 MFMAs.
-            //   0: one MFMA, then its share of the others (the wino4_kernel pattern)   1: groups of 4 MFMAs
-            //   2: the 12 MFMAs as one burst, everything else behind it               3: compiler's own order
-#ifndef ST3D_W43_SCHED
-#define ST3D_W43_SCHED 3
 #endif
-            constexpr int MG = ST3D_W43_SCHED == 0 ? 1 : (ST3D_W43_SCHED == 1 ? 4 : 12);
-            if (ST3D_W43_SCHED != 3) {
-#pragma unroll
-                for (int i_ = 0; i_ < 12 / MG; ++i_) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, MG, 0);
-                    if (kk == 0) __builtin_amdgcn_sched_group_barrier(0x120, MG, 0);       // the stage's loads + LDS reads
-                    else if (kk == NK6 - 1) {
-                        __builtin_amdgcn_sched_group_barrier(0x002, 3 * MG, 0);            // gate + row transform + column transform
-                        __builtin_amdgcn_sched_group_barrier(0x320, MG, 0);                // LDS reads / writes, filter loads
-                    } else __builtin_amdgcn_sched_group_barrier(0x126, MG, 0);
-                }
-            }
+            if (kk == 0) W6_GLOAD(sc);
+#if !(defined(ST3D_W43_DIAG) && ST3D_W43_DIAG == 9)
+            if (kk & 1) vcompute(trow, vcur); else vcompute(trow, vnext);
+#else
+            if (kk & 1) { vcur[0] = vnext[1]; vcur[1] = vnext[2]; vcur[2] = vnext[0]; } else { vnext[0] = vcur[1]; vnext[1] = vcur[2]; vnext[2] = vcur[0]; }
+#endif
+            if (kk == 3) W6_LSTORE(pb2);
             __builtin_amdgcn_sched_barrier(0);
         }
+#if !(defined(ST3D_W43_DIAG) && ST3D_W43_DIAG == 8)        // 8: no barrier between stages
         __syncthreads();
+#endif
     };
-    int c = 0;
-    for (; c + 3 <= nstages; c += 3) {
-        stage(c, std::integral_constant<int, 0>{});
-        stage(c + 1, std::integral_constant<int, 1>{});
-        stage(c + 2, std::integral_constant<int, 2>{});
-    }
-    if (c < nstages) stage(c, std::integral_constant<int, 0>{});
-    if (c + 1 < nstages) stage(c + 1, std::integral_constant<int, 1>{});
-#undef W6_MFMAS
-
     // ---- epilogue.  Along b (this wave's three b): z_j = sum_b A^T[j][b] m_b, A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
     //   bh 0 (b 0 1 2): z0 = m0 + s, z1 = z3 = d, z2 = s            with s = m1 + m2, d = m1 - m2
     //   bh 1 (b 3 4 5): z0 = s, z1 = 2 d, z2 = 4 s, z3 = 8 d + m5   with s = m3 + m4, d = m3 - m4
-    // then per output column j one exchange [a][co][tile][bh]; readers sum the two halves and apply A^T along a.
-    float *ex = smem;
-    constexpr int NIT = 2;                         // 4x4 output tiles per reader thread (waves 0..7: 512 threads x 2 = 64 co x 16 tiles)
+    // Four exchange passes = (cout half h) x (output column pair jp) through [a 6][co 32][tile 16][bh 2][column 2]: a reader
+    // (512 threads: one 4x4 output tile of the half each) reads (bh 0: z_j z_j+1, bh 1: z_j z_j+1) in ONE 16-byte read, adds
+    // the halves and applies A^T along a on the column PAIR -- packed fp32 math on both sides (writers: pairs of couts), a
+    // quarter of the vector instructions of one-column passes with per-lane selects.  A half's tile is complete after its
+    // two passes and leaves at once: 16 output registers, and the gate of the next half travels under its passes.
+    float *ex = smem + 3 * TSTAGE6;                // its own region: the ring keeps streaming the next tile while a tile is written out
     const bool reader = tid < 512;
-    float yt[NIT][4][4];                           // [item][row i][col j]
-    // the readers' bias and the consumer's ReLU gate (GATE >= 1) are requested NOW: they arrive under the four exchange
-    // passes instead of in front of the stores (one workgroup per CU: an exposed HBM round trip idles the whole CU)
+    auto epilogue = [&](int n, int y0, int x0) __attribute__((always_inline)) {        // (the COMPUTED tile's coordinates)
     const unsigned out_bytes = (unsigned)((size_t)a.Cout * HW * 4);
-    unsigned vo_it[NIT];
-    float bias_it[NIT];
-    f32x4 gq[GATE >= 1 ? NIT : 1][4];
-    if (reader) {
-        __amdgpu_buffer_rsrc_t rg = rx;
-        if (GATE >= 1) rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.gate + (size_t)n * a.Cout * HW), 0, out_bytes, 0x00020000);
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int q = tid + 512 * it, col = q >> 4, tl = q & 15;
-            const int ox = x0 + 4 * tl;
-            const bool inb = y0 < H && ox < W;           // H % 4 == 0, W % 64 == 0: always (kept for the descriptor sentinel)
-            vo_it[it] = inb ? (unsigned)((((size_t)co0 + col) * HW + (size_t)y0 * W + ox) * 4) : kOob;
-            bias_it[it] = a.bias ? a.bias[co0 + col] : 0.f;
-            if (GATE >= 1 && it == 0) {       // (the second item's gate is requested behind the passes: 16 more live registers spill)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    gq[it][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, vo_it[it], (unsigned)(i * W * 4), 0));
-            }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float m0 = acc[0][cb][r], m1 = acc[1][cb][r], m2 = acc[2][cb][r];
-                float z;
-                if (bh == 0) z = j == 0 ? m0 + (m1 + m2) : (j == 2 ? m1 + m2 : m1 - m2);
-                else z = j == 0 ? m0 + m1 : (j == 1 ? 2.f * (m0 - m1) : (j == 2 ? 4.f * (m0 + m1) : 8.f * (m0 - m1) + m2));
-                const int co = cb * 16 + 4 * kq + r;
-                ex[((wa * 64 + co) * 16 + tx) * 2 + bh] = z;
-            }
-        __syncthreads();
-        if (reader) {
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int q = tid + 512 * it, co = q >> 4, tl = q & 15;
-                float zs[6];
-#pragma unroll
-                for (int aa = 0; aa < 6; ++aa) {
-                    const f32x2 v = *reinterpret_cast<const f32x2 *>(&ex[((aa * 64 + co) * 16 + tl) * 2]);
-                    zs[aa] = v[0] + v[1];
-                }
-                const float s12 = zs[1] + zs[2], d12 = zs[1] - zs[2], s34 = zs[3] + zs[4], d34 = zs[3] - zs[4];
-                yt[it][0][j] = zs[0] + s12 + s34;
-                yt[it][1][j] = d12 + 2.f * d34;
-                yt[it][2][j] = s12 + 4.f * s34;
-                yt[it][3][j] = d12 + 8.f * d34 + zs[5];
-            }
-        }
-        __syncthreads();
-    }
-    if (!reader) return;
-
-    __amdgpu_buffer_rsrc_t ry = rx, ryp = rx, ryi = rx, rt = rx;
-    if (GATE >= 1) {
-        const __amdgpu_buffer_rsrc_t rg2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.gate + (size_t)n * a.Cout * HW), 0, out_bytes, 0x00020000);
-#pragma unroll
-        for (int it = 1; it < NIT; ++it)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                gq[it][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg2, vo_it[it], (unsigned)(i * W * 4), 0));
-    }
+    const size_t HpWp = (size_t)Hp * Wp;
+    const int col_l = tid >> 4, tl = tid & 15;     // reader: cout within the half, tile
+    const int oy = y0, ox = x0 + 4 * tl;
+    __amdgpu_buffer_rsrc_t rg = ru, ry = ru, ryp = ru, ryi = ru, rt = ru;
+    if (GATE >= 1) rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.gate + (size_t)n * a.Cout * HW), 0, out_bytes, 0x00020000);
     if (a.y) ry = __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)n * a.Cout * HW, 0, out_bytes, 0x00020000);
     if (GATE == 2) rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.addt + (size_t)n * a.Cout * HW), 0, out_bytes, 0x00020000);
-    const size_t HpWp = (size_t)Hp * Wp;
     if (EPI == 1) {
         ryp = __builtin_amdgcn_make_buffer_rsrc(a.yp + (size_t)n * a.Cout * HpWp, 0, (unsigned)(a.Cout * HpWp * 4), 0x00020000);
         if (a.yidx) ryi = __builtin_amdgcn_make_buffer_rsrc(a.yidx + (size_t)n * a.Cout * HpWp, 0, (unsigned)(a.Cout * HpWp), 0x00020000);
     }
     const float relu_floor = a.relu ? 0.f : -__builtin_inff();
+    // the reader's bias and the consumer's ReLU gate (GATE >= 1) of a half are requested two passes before they are used
+    // (one workgroup per CU: an exposed HBM round trip idles the whole CU)
+    unsigned vo = kOob;
+    float bsum = 0.f;
+    f32x4 gq[GATE >= 1 ? 4 : 1];
+    auto request = [&](int h) __attribute__((always_inline)) {
+        const int col = 32 * h + col_l;
+        const bool inb = reader && y0 < H && ox < W;   // H % 4 == 0, W % 64 == 0: every reader (kept for the descriptor sentinel)
+        vo = inb ? (unsigned)((((size_t)co0 + col) * HW + (size_t)y0 * W + ox) * 4) : kOob;
+#if defined(ST3D_W43_DIAG) && ST3D_W43_DIAG == 4       // diagnostic build: gate reads and output stores out of range (issued, no memory traffic)
+        if (a.N >= 0) vo = kOob;
+#endif
+        bsum = (reader && a.bias) ? a.bias[co0 + col] : 0.f;
+        if (GATE >= 1) {
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int q = tid + 512 * it, col = q >> 4, tl = q & 15;
-        const int oy = y0, ox = x0 + 4 * tl;
-        const unsigned vo = vo_it[it];
-        const bool inb = vo != kOob;
-        const float bsum = bias_it[it];
-        f32x4 rowv[4];
+            for (int i = 0; i < 4; ++i)
+                gq[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, W43_GATE_VO(vo), (unsigned)(i * W * 4), 0));
+        }
+    };
+    request(0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+    for (int h = 0; h < 2; ++h) {
+        f32x4 rowv[4];                             // [row i] x 4 columns of this reader's tile
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float v = yt[it][i][j] + bsum;
-                if (GATE == 0) v = __builtin_fmaxf(v, relu_floor);
-                rowv[i][j] = v;
-            }
-            if (GATE >= 1) {
-                const f32x4 g = gq[it][i];
-                if (GATE == 2) {
-                    const f32x4 tg = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rt, vo, (unsigned)(i * W * 4), 0));
+        for (int jp = 0; jp < 2; ++jp) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        // unfused multiply / add (the empty asm keeps the product out of an fma): bitwise what
-                        // st3d_axpy_diff -- built without contraction -- adds
-                        float m = a.addc * (g[j] - tg[j]);
-                        asm volatile("" : "+v"(m));
-                        rowv[i][j] = rowv[i][j] + m;
+            for (int cbi = 0; cbi < 2; ++cbi) {
+                const int cb = 2 * h + cbi;
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const f32x2 m0 = f32x2{acc[0][cb][2 * hh], acc[0][cb][2 * hh + 1]};
+                    const f32x2 m1 = f32x2{acc[1][cb][2 * hh], acc[1][cb][2 * hh + 1]};
+                    const f32x2 m2 = f32x2{acc[2][cb][2 * hh], acc[2][cb][2 * hh + 1]};
+                    f32x2 za, zb;                  // columns 2 jp, 2 jp + 1 for couts r = 2 hh, 2 hh + 1
+                    if (bh == 0) {
+                        asm volatile("");          // (a real scalar branch: both arms computed and selected per lane otherwise)
+                        const f32x2 sm = m1 + m2, dm = m1 - m2;
+                        za = jp == 0 ? m0 + sm : sm;
+                        zb = dm;
+                    } else {
+                        asm volatile("");
+                        const f32x2 sm = m0 + m1, dm = m0 - m1;
+                        za = jp == 0 ? sm : 4.f * sm;
+                        zb = jp == 0 ? 2.f * dm : 8.f * dm + m2;
+                    }
+#pragma unroll
+                    for (int rr = 0; rr < 2; ++rr) {
+                        const int col = cbi * 16 + 4 * kq + 2 * hh + rr;
+                        // (tiles 8..15 keep their halves swapped: sixteen lanes' 8-byte stores then cover all 32 banks;
+                        //  the reader adds the halves, in either order)
+                        float *pz = &ex[((wa * 32 + col) * 16 + tx) * 4 + 2 * (bh ^ (tx >> 3))];
+                        pz[0] = za[rr];
+                        pz[1] = zb[rr];
                     }
                 }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) rowv[i][j] = g[j] > 0.f ? rowv[i][j] : 0.f;
             }
-            // (row offset in the VECTOR offset, scalar offset 0: with an SGPR scalar offset the compiler assumes the 16-byte
-            //  store has read its data registers at issue and reuses them for the next row at once -- on gfx950 the last
-            //  lanes of the store then picked up the next row's values now and then: rowv[1][0] came out as rowv[2][2])
-            if (a.y) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rowv[i]), ry, inb ? vo + (unsigned)(i * W * 4) : kOob, 0, 0);
-        }
-        if (EPI == 1) {     // MaxPool2d(2,2): first maximum in row-major window order (ATen); four windows per 4x4 tile
-            const unsigned vp = inb ? (unsigned)((((size_t)co0 + col) * HpWp + (size_t)(oy >> 1) * Wp + (ox >> 1)) * 4) : kOob;
+            __syncthreads();
+            if (reader) {
+                f32x2 zs[6];
 #pragma unroll
-            for (int pi = 0; pi < 2; ++pi) {
-                f32x2 best; unsigned bidx = 0;
-#pragma unroll
-                for (int pj = 0; pj < 2; ++pj) {
-                    const float w00 = rowv[2 * pi][2 * pj], w01 = rowv[2 * pi][2 * pj + 1];
-                    const float w10 = rowv[2 * pi + 1][2 * pj], w11 = rowv[2 * pi + 1][2 * pj + 1];
-                    float bv = w00; int bi = 0;
-                    if (w01 > bv || w01 != w01) { bv = w01; bi = 1; }
-                    if (w10 > bv || w10 != w10) { bv = w10; bi = 2; }
-                    if (w11 > bv || w11 != w11) { bv = w11; bi = 3; }
-                    best[pj] = bv; bidx |= (unsigned)(bi << (8 * pj));
+                for (int aa = 0; aa < 6; ++aa) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(&ex[((aa * 32 + col_l) * 16 + tl) * 4]);
+                    zs[aa] = f32x2{v[0], v[1]} + f32x2{v[2], v[3]};
                 }
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, best), ryp, vp, (unsigned)(pi * Wp * 4), 0);
-                if (a.yidx) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)bidx, ryi, vp == kOob ? kOob : vp / 4, (unsigned)(pi * Wp), 0);
+                const f32x2 s12 = zs[1] + zs[2], d12 = zs[1] - zs[2], s34 = zs[3] + zs[4], d34 = zs[3] - zs[4];
+                const f32x2 r0 = zs[0] + s12 + s34, r1 = d12 + 2.f * d34, r2 = s12 + 4.f * s34, r3 = d12 + 8.f * d34 + zs[5];
+                rowv[0][2 * jp] = r0[0]; rowv[0][2 * jp + 1] = r0[1];
+                rowv[1][2 * jp] = r1[0]; rowv[1][2 * jp + 1] = r1[1];
+                rowv[2][2 * jp] = r2[0]; rowv[2][2 * jp + 1] = r2[1];
+                rowv[3][2 * jp] = r3[0]; rowv[3][2 * jp + 1] = r3[1];
+            }
+            __syncthreads();
+        }
+#if defined(ST3D_W43_DIAG) && ST3D_W43_DIAG == 3       // diagnostic build: exchange passes, no global loads / stores -- wrong results, timing only
+        if (a.N < 0) { float sacc = 0.f; for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) sacc += rowv[i][j]; ex[tid] = sacc; }
+        if (h == 1) { uload(0, u4[0]); uload(1, u4[1]); uload(2, u4[2]); }
+        continue;
+#endif
+        // the accumulators are dead: the next tile's first three filter-operand sets travel under the last stores
+        if (h == 1) { uload(0, u4[0]); uload(1, u4[1]); uload(2, u4[2]); }
+        if (reader) {
+            const int col = 32 * h + col_l;
+            const bool inb = vo != kOob;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = rowv[i][j] + bsum;
+                    if (GATE == 0) v = __builtin_fmaxf(v, relu_floor);
+                    rowv[i][j] = v;
+                }
+                if (GATE >= 1) {
+                    const f32x4 g = gq[i];
+                    if (GATE == 2) {
+                        const f32x4 tg = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rt, vo, (unsigned)(i * W * 4), 0));
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            // unfused multiply / add (the empty asm keeps the product out of an fma): bitwise what
+                            // st3d_axpy_diff -- built without contraction -- adds
+                            float m = a.addc * (g[j] - tg[j]);
+                            asm volatile("" : "+v"(m));
+                            rowv[i][j] = rowv[i][j] + m;
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) rowv[i][j] = g[j] > 0.f ? rowv[i][j] : 0.f;
+                }
+                // (row offset in the VECTOR offset, scalar offset 0: with an SGPR scalar offset the compiler assumes the 16-byte
+                //  store has read its data registers at issue and reuses them for the next row at once -- on gfx950 the last
+                //  lanes of the store then picked up the next row's values now and then: rowv[1][0] came out as rowv[2][2])
+                if (a.y) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rowv[i]), ry, inb ? vo + (unsigned)(i * W * 4) : kOob, 0, 0);
+            }
+            if (EPI == 1) {     // MaxPool2d(2,2): first maximum in row-major window order (ATen); four windows per 4x4 tile
+                const unsigned vp = inb ? (unsigned)((((size_t)co0 + col) * HpWp + (size_t)(oy >> 1) * Wp + (ox >> 1)) * 4) : kOob;
+#pragma unroll
+                for (int pi = 0; pi < 2; ++pi) {
+                    f32x2 best; unsigned bidx = 0;
+#pragma unroll
+                    for (int pj = 0; pj < 2; ++pj) {
+                        const float w00 = rowv[2 * pi][2 * pj], w01 = rowv[2 * pi][2 * pj + 1];
+                        const float w10 = rowv[2 * pi + 1][2 * pj], w11 = rowv[2 * pi + 1][2 * pj + 1];
+                        float bv = w00; int bi = 0;
+                        if (w01 > bv || w01 != w01) { bv = w01; bi = 1; }
+                        if (w10 > bv || w10 != w10) { bv = w10; bi = 2; }
+                        if (w11 > bv || w11 != w11) { bv = w11; bi = 3; }
+                        best[pj] = bv; bidx |= (unsigned)(bi << (8 * pj));
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, best), ryp, vp, (unsigned)(pi * Wp * 4), 0);
+                    if (a.yidx) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)bidx, ryi, vp == kOob ? kOob : vp / 4, (unsigned)(pi * Wp), 0);
+                }
             }
         }
+        if (h == 0) request(1);
+    }
+    };      // epilogue
+
+    // ---- the stream: tile after tile of this workgroup's slot
+    int pb = 0;
+    for (int cpix = slot; cpix < npix; cpix += nslots) {
+        for (int c = 0; c < nstages; ++c) {
+            int sc = c + 2;
+            if (sc == nstages) { spix += nslots; stage_tile(spix); }      // the staging runs on into the next tile's patch
+            if (sc >= nstages) sc -= nstages;
+            stage(c, sc, pb);
+            pb = pb == 2 ? 0 : pb + 1;
+        }
+        int cn, cy0, cx0;
+        decode(cpix, cn, cy0, cx0);
+#if defined(ST3D_W43_DIAG) && ST3D_W43_DIAG == 2       // diagnostic build: no epilogue at all -- no results, timing only
+        if (a.N < 0) { float sacc = 0.f; for (int b = 0; b < 3; ++b) for (int cb = 0; cb < 4; ++cb) for (int r = 0; r < 4; ++r) sacc += acc[b][cb][r]; ex[tid] = sacc; }
+        uload(0, u4[0]); uload(1, u4[1]); uload(2, u4[2]);
+#else
+        epilogue(cn, cy0, cx0);
+#endif
+        // (the staged tile's addresses are recomputed rather than carried through the epilogue's register peak)
+        asm volatile("" : "+s"(spix));
+        stage_tile(spix);
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) acc[b][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 }
 
@@ -467,7 +541,7 @@ __global__ void wino43_pack_kernel(const float *__restrict__ w, int Cout, int Ci
 }
 
 bool shape_ok43(int Cin, int Cout, int H, int W) {
-    return Cin >= 2 * KS6 && (Cin % KS6) == 0 && (Cout % 64) == 0 && (H % 4) == 0 && (W % 64) == 0 && H > 0 && W > 0 &&
+    return Cin >= 4 * KS6 && (Cin % KS6) == 0 && (Cout % 64) == 0 && (H % 4) == 0 && (W % 64) == 0 && H > 0 && W > 0 &&
            (unsigned long long)Cin * (unsigned long long)H * (unsigned long long)W * 4ull < (1ull << 31) &&
            (unsigned long long)Cout * (unsigned long long)H * (unsigned long long)W * 4ull < (1ull << 31);
 }
@@ -477,8 +551,20 @@ int launch_wino43(Wino43Args a, hipStream_t s) {
     a.tiles_x = a.W / T6_COLS;
     a.tiles_y = a.H / T6_ROWS;
     a.n_ct = a.Cout / 64;
-    const long blocks = (long)a.n_ct * a.tiles_x * a.tiles_y * a.N;
-    constexpr size_t kSmem = (size_t)SMEM6 * sizeof(float);       // 81 KB of dynamic LDS: opt in once per instantiation
+    a.magic_x = (unsigned)((1ull << 32) / (unsigned)a.tiles_x + 1ull);      // (tiles_x == 1: unused)
+    a.magic_y = (unsigned)((1ull << 32) / (unsigned)a.tiles_y + 1ull);
+    // one persistent workgroup per CU: n_ct cout tiles x nslots slots, each slot walking npix / nslots pixel tiles
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    const long npix = (long)a.tiles_x * a.tiles_y * a.N;
+    long nslots = cus / a.n_ct;
+    if (const char *e = getenv("ST3D_W43_SLOTS")) nslots = atol(e);       // lab: 0 = one workgroup per tile
+    if (nslots < 1 || nslots > npix) nslots = npix;
+    const long blocks = (long)a.n_ct * nslots;
+    constexpr size_t kSmem = (size_t)SMEM6 * sizeof(float);       // dynamic LDS above the 64 KB static limit: opt in once per instantiation
     auto go = [&](auto kernel) -> int {
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmem);
         if (attr != hipSuccess) { st3d::set_error("wino43: hipFuncSetAttribute(MaxDynamicSharedMemorySize): %s", hipGetErrorString(attr)); return ST3D_E_HIP; }

@@ -22,7 +22,9 @@ def dev():
 
 @pytest.fixture(scope="module")
 def ops():
-    from st3d import ops as o
+    from st3d import _lib, ops as o
+    if os.environ.get("ST3D_DIAG_LIB"):          # lab: the same tests against an A/B build of the library (tools/w43_ab_build.sh)
+        _lib.SO_PATH = os.path.abspath(os.environ["ST3D_DIAG_LIB"])
     return o
 
 
@@ -537,11 +539,16 @@ def test_wino_fused_pool_and_unpool(dev, ops, N, Cin, Cout, H, W):
 # ---------------------------------------------------------------------------- Winograd F(4x4,3x3) conv (round 3)
 @pytest.mark.parametrize("N,Cin,Cout,H,W", [(1, 64, 64, 4, 64), (2, 128, 64, 8, 64), (1, 256, 256, 16, 128), (1, 512, 512, 64, 64),
                                              (2, 128, 256, 12, 192)])
-def test_wino43_fwd_and_chain_dgrad(dev, ops, N, Cin, Cout, H, W):
+@pytest.mark.parametrize("slots", ["", "1", "4"])
+def test_wino43_fwd_and_chain_dgrad(dev, ops, monkeypatch, N, Cin, Cout, H, W, slots):
     """F(4x4,3x3) kernel (csrc/wino43.hip) against an fp64 direct convolution at the SAME tolerance as the F(2x2,3x3)
     kernel (3e-5 of the output scale forward, 5e-5 input-gradient; measured ~1e-5 at K = 512), the fused pool against the
     separate pool kernel (bitwise), the producer-side output gate / content term and the fused unpool against the plain
-    launch on pre-processed operands (bitwise: same arithmetic), and against the F(2x2,3x3) kernel on the same inputs."""
+    launch on pre-processed operands (bitwise: same arithmetic), and against the F(2x2,3x3) kernel on the same inputs.
+    slots: persistent workgroups per cout tile (default: CUs / cout tiles) -- "1" and "4" make one workgroup walk many pixel
+    tiles, ragged (18 tiles over 4 slots), so the stream of stages runs across tile boundaries on these small shapes too."""
+    if slots:
+        monkeypatch.setenv("ST3D_W43_SLOTS", slots)
     torch.manual_seed(Cin + Cout + H)
     x = torch.randn(N, Cin, H, W, dtype=torch.float64, requires_grad=True)
     w = (torch.randn(Cout, Cin, 3, 3) * (2.0 / (Cin * 9)) ** 0.5).double()
@@ -585,7 +592,7 @@ def test_wino43_fwd_and_chain_dgrad(dev, ops, N, Cin, Cout, H, W):
     assert torch.equal(ops.wino43_dgrad_chain(gp, ud, Cin, pool_idx=pidx, out_gate=og),
                        ops.wino43_dgrad_chain(up, ud, Cin, out_gate=og))
     # shapes outside the tiling are refused, not mis-computed
-    assert ops._lib.load().st3d_wino43_supported(Cin, Cout, H, W + 32) == 0 and ops._lib.load().st3d_wino43_supported(8, Cout, H, W) == 0
+    assert ops._lib.load().st3d_wino43_supported(Cin, Cout, H, W + 32) == 0 and ops._lib.load().st3d_wino43_supported(48, Cout, H, W) == 0
 
 
 # ---------------------------------------------------------------------------- general soft renderer (K faces / pixel, blur)
@@ -1110,7 +1117,9 @@ def test_gram_bwd_gated_zeroes_exactly_the_closed_gates(dev, ops, B, C, H, W):
 
 def test_plan_backward_with_producer_side_gates_is_bitwise_the_plain_one(dev, golden_dir, monkeypatch):
     """The loss plan's backward with the gates at the producers + the fused relu1_1/conv1_1 kernel (defaults) against
-    ST3D_PREGATE=0 (bitwise: zeros are zeros) and against ST3D_TAP0_FUSED=0 (another summation order: 1e-5)."""
+    ST3D_PREGATE=0 (bitwise: zeros are zeros) and against ST3D_TAP0_FUSED=0 (another summation order: 1e-5).  The bitwise
+    comparison holds between runs on the SAME conv kernels: the un-gated chain has no F(4x4,3x3) path, so it is made with
+    ST3D_WINO43=0; the default plan (F(4x4,3x3) at conv1_2 here) is compared with it at the kernels' tolerance."""
     from st3d import vgg as V
     g = torch.Generator().manual_seed(3)
     x = torch.rand(2, 3, 64, 64, generator=g).to(dev)
@@ -1118,7 +1127,7 @@ def test_plan_backward_with_producer_side_gates_is_bitwise_the_plain_one(dev, go
     sty = torch.rand(1, 3, 64, 64, generator=g).to(dev)
 
     def run(env):
-        for k in ("ST3D_PREGATE", "ST3D_TAP0_FUSED"):
+        for k in ("ST3D_PREGATE", "ST3D_TAP0_FUSED", "ST3D_WINO43"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -1128,9 +1137,12 @@ def test_plan_backward_with_producer_side_gates_is_bitwise_the_plain_one(dev, go
         plan.set_style(sty, 2)
         loss, grad = plan.loss(x, 1e6, 1.0)
         return loss.clone(), grad.clone()
-    l0, g0 = run({})
-    l1, g1 = run({"ST3D_PREGATE": "0"})
-    l2, g2 = run({"ST3D_PREGATE": "0", "ST3D_TAP0_FUSED": "0"})
+    l0, g0 = run({"ST3D_WINO43": "0"})
+    l1, g1 = run({"ST3D_WINO43": "0", "ST3D_PREGATE": "0"})
+    l2, g2 = run({"ST3D_WINO43": "0", "ST3D_PREGATE": "0", "ST3D_TAP0_FUSED": "0"})
     assert torch.equal(l0, l1) and torch.equal(g0, g1)
     assert torch.equal(l0, l2)
     _scale_close(g0, g2, 1e-5, "fused vs unfused bottom of the backward")
+    l3, g3 = run({})
+    assert float((l3 - l0).abs().max() / l0.abs().max()) < 1e-5
+    _scale_close(g3, g0, 5e-5, "F(4x4,3x3) vs F(2x2,3x3) plan")

@@ -6,7 +6,9 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "2d-to-3d-style-transfer_amd"))
 import torch
-from st3d import ops
+from st3d import ops, _lib
+if os.environ.get("ST3D_DIAG_LIB"):          # a diagnostic build of the library (tools/w43_diag.sh): timing only
+    _lib.SO_PATH = os.environ["ST3D_DIAG_LIB"]
 B = int(os.environ.get("B", "8")); S = int(os.environ.get("S", "512"))
 dev = torch.device("cuda:0")
 # (name, Cin, Cout, divisor, pooled_after, grad_arrives_pooled)
