@@ -521,7 +521,7 @@ def main():
             "traffic": (traffic["fetch_bytes_raw_per_step"] + traffic["write_bytes_per_step"]) if traffic else None,
             "traffic_source": tsrc,
             "note": "whole step per GPU (renders, losses, Adam and host gaps included): MFMA flops issued per step (%.1f GF: "
-                    "Winograd convs 16/36 of the direct count, Gram forward upper tiles only) over the HIP-event time of the "
+                    "Winograd convs 16/36 (F(2x2,3x3)) or 36/144 (F(4x4,3x3)) of the direct count, Gram forward upper tiles only) over the HIP-event time of the "
                     "timed region (%.3f ms/step); alg_equiv_tflops prices the same time with the direct-convolution count of "
                     "SURVEY.md 8d (%.1f GF/step)" % (f_issued_step / 1e9, dev_ms / args.steps, f_alg_step / 1e9)}
         roofline = step_roofline

@@ -12,7 +12,7 @@ between them).  Per dispatch:
   gui_cycles   = GRBM_GUI_ACTIVE / n_xcc                        (the rocprofv3 row is the SUM over the 8 XCCs)
   mfma_util    = busy_cycles / (gui_cycles * 1024 SIMDs)        (rocprofv3's MfmaUtil expression with SIMD_NUM = 256 CUs x 4)
 The counted flops are compared with the ANALYTIC issued count bench.py prices (16/36 of the direct convolution for the
-Winograd launches, padded tiles included in what is counted), and -- given an un-profiled bench line with --layers --
+F(2x2,3x3) launches, 36/144 for the F(4x4,3x3) ones, padded tiles included in what is counted), and -- given an un-profiled bench line with --layers --
 with the HIP-event time of the same launches: counted flops / un-profiled time / 157.3 TF/s must tell the same story as
 `roofline.frac`.
 """
@@ -59,7 +59,7 @@ def main():
         util = busy / (gui * N_SIMD) if gui else 0.0
         k = short(name)
         rows.append((k, grid // wg, flops, busy, gui, util, ns))
-        f = fam["wino4_kernel" if "wino4_kernel" in k else k.split("<")[0]]
+        f = fam["wino43_kernel" if "wino43_kernel" in k else "wino4_kernel" if "wino4_kernel" in k else k.split("<")[0]]
         f[0] += flops; f[1] += busy; f[2] += gui; f[3] += 1; f[4] += ns
     with open(prefix + "_per_dispatch.csv", "w") as fh:
         fh.write("kernel,workgroups,mfma_flops_counted,mfma_busy_cycles,gui_cycles_per_xcc,mfma_util,duration_ns_under_pmc\n")
@@ -73,24 +73,42 @@ def main():
             continue
         out["families"][k] = {"launches": n, "mfma_flops_counted": flops, "mfma_busy_cycles": busy,
                               "gui_cycles_per_xcc": gui, "mfma_util": round(busy / (gui * N_SIMD), 4) if gui else None,
-                              # a v_mfma_f32_32x32x2_f32 is 4096 flops and occupies its SIMD's matrix pipe for 64 cycles (16 passes)
+                              # a v_mfma_f32_32x32x2_f32 is 4096 flops and occupies its SIMD's matrix pipe for 64 cycles (16 passes);
+                              # a v_mfma_f32_16x16x4_f32 (wino43_kernel) is 2048 flops in 32 cycles: the same 64 per 4096
                               "busy_cycles_per_4096_flops": round(busy / (flops / 4096.0), 2) if flops else None,
                               "duration_ms_under_pmc": round(ns * 1e-6, 4)}
-    w = out["families"].get("wino4_kernel")
-    if w:
+    w4, w6 = out["families"].get("wino4_kernel"), out["families"].get("wino43_kernel")
+    if w4 or w6:
+        # the default plan at 8 x 512^2: F(4x4,3x3) (36/144 of the direct count) where Cin >= 64 and W % 64 == 0 -- conv1_2 ..
+        # conv4_4 -- and F(2x2,3x3) (16/36) for conv5_1 (W = 32); forward + input gradient each.  Without the wino43 family in
+        # the trace (ST3D_WINO43=0) every layer is priced as F(2x2,3x3).
         S, B = 512, 8
         convs = [(64, 64, 1), (64, 128, 2), (128, 128, 2), (128, 256, 4), (256, 256, 4), (256, 256, 4), (256, 256, 4), (256, 512, 8),
                  (512, 512, 8), (512, 512, 8), (512, 512, 8), (512, 512, 16)]
-        analytic = sum(2.0 * 9 * ci * co * (S // d) ** 2 * B for ci, co, d in convs) * 2 * 16.0 / 36.0
-        w["mfma_flops_analytic_issued"] = analytic
-        w["counted_over_analytic"] = round(w["mfma_flops_counted"] / analytic, 4)
-        w["avg_flops_per_launch_counted"] = w["mfma_flops_counted"] / w["launches"]
+        direct = lambda ci, co, d: 2.0 * 9 * ci * co * (S // d) ** 2 * B
+        on43 = lambda ci, co, d: w6 is not None and ci >= 64 and (S // d) % 64 == 0
+        a4 = sum(direct(*c) for c in convs if not on43(*c)) * 2 * 16.0 / 36.0
+        a6 = sum(direct(*c) for c in convs if on43(*c)) * 2 * 36.0 / 144.0
+        for w, an in ((w4, a4), (w6, a6)):
+            if w:
+                w["mfma_flops_analytic_issued"] = an
+                w["counted_over_analytic"] = round(w["mfma_flops_counted"] / an, 4)
+                w["avg_flops_per_launch_counted"] = w["mfma_flops_counted"] / w["launches"]
+        both = {"launches": sum(w["launches"] for w in (w4, w6) if w),
+                "mfma_flops_counted": sum(w["mfma_flops_counted"] for w in (w4, w6) if w),
+                "mfma_flops_analytic_issued": a4 + a6,
+                "mfma_busy_cycles": sum(w["mfma_busy_cycles"] for w in (w4, w6) if w),
+                "gui_cycles_per_xcc": sum(w["gui_cycles_per_xcc"] for w in (w4, w6) if w),
+                "duration_ms_under_pmc": round(sum(w["duration_ms_under_pmc"] for w in (w4, w6) if w), 4)}
+        both["counted_over_analytic"] = round(both["mfma_flops_counted"] / both["mfma_flops_analytic_issued"], 4)
+        both["mfma_util"] = round(both["mfma_busy_cycles"] / (both["gui_cycles_per_xcc"] * N_SIMD), 4)
         if line and line.get("roofline", {}).get("ms_per_step"):
             ms = line["roofline"]["ms_per_step"]
-            w["unprofiled_ms_per_step_hip_events"] = ms
-            w["counted_tflops_over_unprofiled_time"] = round(w["mfma_flops_counted"] / (ms * 1e-3) / 1e12, 2)
-            w["counted_frac_of_fp32_mfma_peak"] = round(w["mfma_flops_counted"] / (ms * 1e-3) / PEAK, 4)
-            w["bench_line_roofline_frac"] = line["roofline"]["frac"]
+            both["unprofiled_ms_per_step_hip_events"] = ms
+            both["counted_tflops_over_unprofiled_time"] = round(both["mfma_flops_counted"] / (ms * 1e-3) / 1e12, 2)
+            both["counted_frac_of_fp32_mfma_peak"] = round(both["mfma_flops_counted"] / (ms * 1e-3) / PEAK, 4)
+            both["bench_line_roofline_frac"] = line["roofline"]["frac"]
+        out["winograd_convs"] = both
     tot = sum(v["mfma_flops_counted"] for v in out["families"].values())
     out["mfma_flops_counted_per_step"] = tot
     json.dump(out, open(prefix + ".json", "w"), indent=1)
