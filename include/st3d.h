@@ -21,7 +21,9 @@
  * measured-best paths; every other value exists for same-box A/B runs and gives the same
  * results (to fp32 summation order where a split count changes).
  *   ST3D_CONV=direct            direct implicit-GEMM convolutions (conv.hip) instead of Winograd
- *   ST3D_WINO_MAP=rr|xcd        block -> tile mapping of the Winograd launches
+ *   ST3D_WINO43=0, ST3D_WINO43_MINK=k   never run the F(4x4,3x3) Winograd kernel (wino43.hip) / only from k input channels (default 64)
+ *   ST3D_W43_SLOTS=n            persistent workgroups per cout tile of the F(4x4,3x3) kernel (default: CUs / cout tiles)
+ *   ST3D_WINO_MAP=rr|xcd        block -> tile mapping of the F(2x2,3x3) Winograd launches
  *   ST3D_PREGATE=0              every input-gradient applies its own ReLU gate (consumer side)
  *   ST3D_TAP0_FUSED=0, ST3D_TAP0_J=1   separate relu1_1 Gram backward + conv1_1 input gradient / 4-byte accesses
  *   ST3D_GRAM_MULTI=0           the five Gram forwards as separate launches (st3d_gram_fwd_multi)
@@ -253,8 +255,9 @@ int st3d_wino_dgrad_chain(const float *gy, const float *act, const uint8_t *pool
                           const float *u_dgrad, const float *out_gate, const float *add_target, float add_coef,
                           float *gx, int N, int Cin, int Cout, int H, int W, st3d_stream_t stream);
 /* The same convolutions as Winograd F(4x4,3x3) (csrc/wino43.hip, round 3): 2.25 instead of 4 MFMA-multiplies per output
- * pixel, fp32 throughout (<= 1.3e-5 of the output scale against an fp64 convolution at K = 512).  Shapes: Cin >= 16,
- * Cin % 8 == 0, Cout % 64 == 0 (both % 64 for the pack), H % 4 == 0, W % 64 == 0.  Own filter pack (36 floats per weight).
+ * pixel, fp32 throughout (<= 1.3e-5 of the output scale against an fp64 convolution at K = 512).  Shapes: Cin >= 64,
+ * Cin % 16 == 0, Cout % 64 == 0 (both % 64 for the pack), H % 4 == 0, W % 64 == 0, each tensor < 2^31 bytes per image
+ * (st3d_wino43_supported).  Own filter pack (36 floats per weight).  One persistent workgroup per CU.
  * st3d_wino43_dgrad_chain takes an already gated gradient (or, with pool_idx, the pooled-resolution gradient) exactly as
  * st3d_wino_dgrad_chain does with act == pooled == NULL. */
 int st3d_wino43_supported(int Cin, int Cout, int H, int W);
