@@ -94,12 +94,15 @@ __device__ __forceinline__ void bt6(T d0, T d1, T d2, T d3, T d4, T d5, T &t0, T
 #define W43_GATE_VO(v) (v)
 #endif
 
-template <int MODE, int EPI, int GATE>
-__global__ __launch_bounds__(NT6, 3) void wino43_kernel(const Wino43Args a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+// (BH = the wave's half of the domain's columns, a template parameter: the kernel branches ONCE per wave into the body of its
+//  half, so the column transform of every k-step and the b-direction of the epilogue are straight-line code in the same basic
+//  block as the k-step's MFMAs instead of two scalar branches behind them)
+template <int MODE, int EPI, int GATE, int BH>
+__device__ __forceinline__ void wino43_body(const Wino43Args &a, float *smem) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (scalar: every role test below is a scalar branch)
-    const int wa = wave >> 1, bh = wave & 1;           // row a of the domain, b half
+    const int wa = wave >> 1;                           // row a of the domain
+    constexpr int bh = BH;                              // b half
     const int tx = lane & 15, kq = lane >> 4;           // MFMA n index (tile) / k index (channel within the k-step)
 
     // PERSISTENT workgroups (one per CU): workgroup (ct, slot) walks the pixel tiles slot, slot + nslots, ... of ONE cout tile,
@@ -250,6 +253,8 @@ __global__ __launch_bounds__(NT6, 3) void wino43_kernel(const Wino43Args a) {
     // request a k-step earlier / the store a stage later through a ring of four 6.85 - 6.95; every request at the head of its
     // k-step instead of behind the MFMAs 7.08.  With the loads out of range (no memory traffic) the sum is 6.1, with no
     // staging at all 5.8: the round trip of the patch rows is worth 10 % (20 % at conv1_2, whose input comes from HBM).
+    // Workgroups of different slots started a fraction of a stage apart (so that the CUs do not all request in the same
+    // microsecond): no change at any delay.
     Staged xs;
     // ---- prologue (once per workgroup): stages 0 and 1 of its first tile, both requests in flight together
     {
@@ -502,6 +507,13 @@ __global__ __launch_bounds__(NT6, 3) void wino43_kernel(const Wino43Args a) {
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb) acc[b][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+}
+
+template <int MODE, int EPI, int GATE>
+__global__ __launch_bounds__(NT6, 3) void wino43_kernel(const Wino43Args a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) wino43_body<MODE, EPI, GATE, 1>(a, smem);
+    else wino43_body<MODE, EPI, GATE, 0>(a, smem);
 }
 
 // w (Cout,Cin,3,3) -> U = G g G^T (6x6, fp64 -> fp32), forward and transposed (180-degree rotated filter, channel roles
