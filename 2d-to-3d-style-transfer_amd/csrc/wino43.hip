@@ -2,13 +2,13 @@
 // (round 3): 36 multiplies per 4x4 output tile = 2.25 per output pixel, against 4 for the F(2x2,3x3) of wino.hip and 9
 // for the direct convolution.  Still fp32 products and fp32 accumulation; the larger transform constants cost about one
 // decimal digit (measured <= 1.3e-5 of the output scale at K = 512 against an fp64 convolution; F(2x2,3x3): 1e-6), inside
-// the 3e-5 the Winograd kernels are tested to.  Used for every layer with Cin >= 64 and W % 64 == 0; narrower maps (conv5_1
-// at 512 x 512) stay on wino4_kernel.
+// the 3e-5 the Winograd kernels are tested to.  Used for every layer with Cin >= 64 and W % 64 == 0 (or W % 32 == 0 with
+// H % 8 == 0: conv5_1 at 512 x 512); other maps stay on wino4_kernel.
 //
 //   Y = A^T [ sum_ci (G g G^T) (.) (B^T d B) ] A       per (cout, 4x4 tile), 6x6 Winograd domain xi = (a, b)
 //
 // Mapping.  One 768-thread workgroup (12 waves, three per SIMD, one workgroup per CU) = 64 cout x 16 tiles (4 rows x 64
-// columns of pixels).  Wave w = (a = w >> 1, bh = w & 1) accumulates row a of the domain for b in {3 bh .. 3 bh + 2} and
+// columns of pixels, or 8 x 32: Geo43).  Wave w = (a = w >> 1, bh = w & 1) accumulates row a of the domain for b in {3 bh .. 3 bh + 2} and
 // all 64 couts on v_mfma_f32_16x16x4_f32 (M = 16 cout, N = 16 tiles, K = 4 input channels): 3 b x 4 cout blocks = 12
 // accumulator tiles = 48 VGPRs, and every B operand feeds FOUR MFMAs.
 //   * B operands V = B^T d B.  The ROW half of the transform (T_a = sum_r B^T[a][r] d[r], 13 VALU per column for all six
@@ -44,18 +44,28 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int NT6 = 768;                 // 12 waves
-constexpr int T6_ROWS = 4, T6_COLS = 64; // output pixels per workgroup: one row of 16 4x4 tiles
 constexpr int KS6 = 16;                  // input channels per stage (four k-steps of 4): one barrier and one staging turn per 48 MFMAs
 constexpr int NK6 = KS6 / 4;
-constexpr int PITCH6 = 76;               // 18 strips of 4 floats (patch columns x0 - 4 .. x0 + 67) stored from index 1: a tile's six
-                                         // columns 4 tx + 3 .. + 8 then start 16-byte aligned (one 16-byte + one 8-byte LDS read)
-constexpr int STRIPS6 = 18;
-constexpr int ITEMS6 = KS6 * STRIPS6;    // 288 staging items (channel, strip) per stage = 576 half-items on 768 threads
-constexpr int TSTAGE6 = KS6 * 6 * PITCH6;        // floats per ring stage: [ci 8][a 6][72]
-constexpr int EX6 = 6 * 64 * 16 * 2;             // exchange floats per output column: [a 6][co 64][tile 16][bh 2]
-constexpr int SMEM6 = 3 * TSTAGE6 + EX6;         // 134 KB (dynamic shared memory): the ring AND the exchange region -- a persistent
-                                                 // workgroup keeps staging its next tile while the finished one is written out
+constexpr int EX6 = 6 * 32 * 16 * 2 * 2;         // exchange floats per pass: [a 6][co 32][tile 16][bh 2][column 2]
+// Tile geometry.  A workgroup step covers 16 4x4 output tiles laid out TC across x TR = 16 / TC down:
+//   TC = 16: 4 x 64 pixels (W % 64 == 0: conv1_2 .. conv4_4 at 512^2), TC = 8: 8 x 32 pixels (W % 32 == 0, H % 8 == 0: conv5_1 at
+//   512^2, conv4_x at the reference's default 768^2).  The ring holds, per channel and tile row, the six row-transformed rows
+//   of the patch columns x0 - 4 .. x0 + 4 TC + 3, stored from index 1 of a PITCH-float row: a tile's six columns 4 t + 3 .. + 8
+//   then start 16-byte aligned (one 16-byte + one 8-byte LDS read).
+template <int TC>
+struct Geo43 {
+    static constexpr int TR = 16 / TC;
+    static constexpr int ROWS = 4 * TR, COLS = 4 * TC;       // output pixels per workgroup step
+    static constexpr int PAIRS = 2 * TC + 4;                 // column pairs per patch row
+    static constexpr int PITCH = 4 * TC + 12;                // 76 / 44
+    static constexpr int CHS = TR * 6 * PITCH;               // floats per channel: 456 / 528
+    static constexpr int TSTAGE = KS6 * CHS;                 // floats per ring stage: 29 / 34 KB
+    static constexpr int HALF_ITEMS = KS6 * TR * PAIRS;      // staging half-items (channel, tile row, column pair) per stage: 576 / 640 of 768 threads
+    static constexpr int SMEM = 3 * TSTAGE + EX6;            // 134 / 147 KB of dynamic LDS: the ring AND the exchange region -- a persistent
+                                                             // workgroup keeps staging its next tile while the finished one is written out
+    static_assert(HALF_ITEMS <= 768 && SMEM * 4 <= 160 * 1024, "tile geometry does not fit the workgroup");
+};
+constexpr int NT6 = 768;                 // 12 waves
 
 struct Wino43Args {
     const float *x;       // MODE 0: (N,Cin,H,W); MODE 3: pooled-resolution gradient (N,Cin,H/2,W/2), already gated
@@ -97,8 +107,9 @@ __device__ __forceinline__ void bt6(T d0, T d1, T d2, T d3, T d4, T d5, T &t0, T
 // (BH = the wave's half of the domain's columns, a template parameter: the kernel branches ONCE per wave into the body of its
 //  half, so the column transform of every k-step and the b-direction of the epilogue are straight-line code in the same basic
 //  block as the k-step's MFMAs instead of two scalar branches behind them)
-template <int MODE, int EPI, int GATE, int BH>
+template <int MODE, int EPI, int GATE, int BH, int TC>
 __device__ __forceinline__ void wino43_body(const Wino43Args &a, float *smem) {
+    using G = Geo43<TC>;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (scalar: every role test below is a scalar branch)
     const int wa = wave >> 1;                           // row a of the domain
@@ -119,7 +130,7 @@ __device__ __forceinline__ void wino43_body(const Wino43Args &a, float *smem) {
         const int r2 = a.tiles_x == 1 ? pix : (int)__umulhi((unsigned)pix, a.magic_x);
         const int txi = pix - r2 * a.tiles_x;
         tn = a.tiles_y == 1 ? r2 : (int)__umulhi((unsigned)r2, a.magic_y);
-        tx0 = txi * T6_COLS; ty0 = (r2 - tn * a.tiles_y) * T6_ROWS;
+        tx0 = txi * G::COLS; ty0 = (r2 - tn * a.tiles_y) * G::ROWS;
     };
     const int H = a.H, W = a.W;
     const size_t HW = (size_t)H * W;
@@ -129,17 +140,18 @@ __device__ __forceinline__ void wino43_body(const Wino43Args &a, float *smem) {
     const int nstages = a.Cin / KS6;
     const unsigned kOob = 0x80000000u;
 
-    // ---- staging: EVERY thread stages one half-item per stage = (channel ci, strip l, column pair h): rows gy = y0 - 1 + r,
-    // columns x0 - 4 + 4 l + 2 h, + 1.  576 half-items on 768 threads: all twelve waves carry the same staging work, so it
-    // sits in the same basic block as their MFMAs (interleaved, no tail behind them) and nobody is late at the barrier.
-    const int s_ci = tid / 36, s_rem = tid - s_ci * 36;
-    const int s_col = 2 * s_rem;                         // = 4 l + 2 h, column offset inside the 72-float strip row
-    const bool s_on = tid < ITEMS6 * 2;
+    // ---- staging: EVERY thread stages one half-item per stage = (channel ci, tile row tr, column pair): rows gy = y0 - 1 +
+    // 4 tr + r, columns x0 - 4 + s_col, + 1.  576 (640) half-items on 768 threads: all twelve waves carry the same staging
+    // work, so it sits in the same basic block as their MFMAs (interleaved, no tail behind them) and nobody is late at the barrier.
+    const int s_ci = tid / (G::TR * G::PAIRS), s_rem = tid - s_ci * (G::TR * G::PAIRS);
+    const int s_tr = s_rem / G::PAIRS;
+    const int s_col = 2 * (s_rem - s_tr * G::PAIRS);     // column offset inside the patch row
+    const bool s_on = tid < G::HALF_ITEMS;
     unsigned voff[6];
     unsigned rowbit[UNPOOL ? 6 : 1];
 #pragma unroll
     for (int r = 0; r < 6; ++r)
-        if (UNPOOL) rowbit[r] = (unsigned)((r + 1) & 1) << 1;        // gy = y0 - 1 + r with y0 % 4 == 0: odd for even r
+        if (UNPOOL) rowbit[r] = (unsigned)((r + 1) & 1) << 1;        // gy = y0 - 1 + 4 tr + r with y0 % 4 == 0: odd for even r
     const unsigned img_bytes = (unsigned)((size_t)a.Cin * in_plane * 4);
     __amdgpu_buffer_rsrc_t rx, ridx;
     // addresses of the staged tile `pix` (>= npix: past this workgroup's last tile -- everything out of range, loads return 0)
@@ -148,7 +160,7 @@ __device__ __forceinline__ void wino43_body(const Wino43Args &a, float *smem) {
         decode(live ? pix : 0, n, y0, x0);
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
-            const int gy = y0 - 1 + r, gx0 = x0 - 4 + s_col;
+            const int gy = y0 - 1 + 4 * s_tr + r, gx0 = x0 - 4 + s_col;
             const bool ok = live && s_on && gy >= 0 && gy < H && gx0 >= 0 && gx0 < W;
             if (UNPOOL) voff[r] = ok ? (unsigned)((s_ci * in_plane + (size_t)(gy >> 1) * Wp + (gx0 >> 1)) * 4) : kOob;   // one pooled element covers the row's two columns
             else voff[r] = ok ? (unsigned)((s_ci * in_plane + (size_t)gy * W + gx0) * 4) : kOob;
@@ -163,7 +175,7 @@ __device__ __forceinline__ void wino43_body(const Wino43Args &a, float *smem) {
 #if defined(ST3D_W43_DIAG) && ST3D_W43_DIAG == 10       // 10: staging loads out of range (issued, no memory traffic)
     if (a.N >= 0) spix = npix;
 #endif
-    const int loff = s_on ? (s_ci * 6 * PITCH6 + s_col + 1) : 0;      // + a * PITCH6 per transformed row (odd index: two 4-byte stores in one ds_write2)
+    const int loff = s_on ? (s_ci * G::CHS + s_tr * 6 * G::PITCH + s_col + 1) : 0;      // + a * PITCH per transformed row (odd index: two 4-byte stores in one ds_write2)
     const unsigned stage_bytes = (unsigned)(KS6 * in_plane * 4);
     const int nksteps = a.Cin / 4;
     const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(
@@ -198,18 +210,18 @@ __device__ __forceinline__ void wino43_body(const Wino43Args &a, float *smem) {
             }
         }
         bt6<f32x2>(d[0], d[1], d[2], d[3], d[4], d[5], t[0], t[1], t[2], t[3], t[4], t[5]);
-        float *dst = &smem[buf * TSTAGE6 + loff];
+        float *dst = &smem[buf * G::TSTAGE + loff];
         if (s_on) {
 #pragma unroll
-            for (int aa = 0; aa < 6; ++aa) { dst[aa * PITCH6] = t[aa][0]; dst[aa * PITCH6 + 1] = t[aa][1]; }
+            for (int aa = 0; aa < 6; ++aa) { dst[aa * G::PITCH] = t[aa][0]; dst[aa * G::PITCH + 1] = t[aa][1]; }
         }
     };
 
     // ---- B operands: this lane's row-a values of (tile tx, channel 4 kk + kq): columns 4 tx + 3 .. 4 tx + 8 of the strip row
-    const int tbase = (kq * 6 + wa) * PITCH6 + 4 * tx;
+    const int tbase = kq * G::CHS + ((tx / TC) * 6 + wa) * G::PITCH + 4 * (tx % TC);
     struct Trow { f32x4 m; f32x2 n; };       // t0..t3, t4..t5
     auto tread = [&](int buf, int kk, Trow &o) __attribute__((always_inline)) {
-        const float *p = &smem[buf * TSTAGE6 + kk * (4 * 6 * PITCH6) + tbase];
+        const float *p = &smem[buf * G::TSTAGE + kk * (4 * G::CHS) + tbase];
         o.m = *reinterpret_cast<const f32x4 *>(p + 4);         // columns 4 tx + 3 .. + 6 of the strip row (stored from index 1)
         o.n = *reinterpret_cast<const f32x2 *>(p + 8);
     };
@@ -329,13 +341,13 @@ __device__ __forceinline__ void wino43_body(const Wino43Args &a, float *smem) {
     // the halves and applies A^T along a on the column PAIR -- packed fp32 math on both sides (writers: pairs of couts), a
     // quarter of the vector instructions of one-column passes with per-lane selects.  A half's tile is complete after its
     // two passes and leaves at once: 16 output registers, and the gate of the next half travels under its passes.
-    float *ex = smem + 3 * TSTAGE6;                // its own region: the ring keeps streaming the next tile while a tile is written out
+    float *ex = smem + 3 * G::TSTAGE;                // its own region: the ring keeps streaming the next tile while a tile is written out
     const bool reader = tid < 512;
     auto epilogue = [&](int n, int y0, int x0) __attribute__((always_inline)) {        // (the COMPUTED tile's coordinates)
     const unsigned out_bytes = (unsigned)((size_t)a.Cout * HW * 4);
     const size_t HpWp = (size_t)Hp * Wp;
     const int col_l = tid >> 4, tl = tid & 15;     // reader: cout within the half, tile
-    const int oy = y0, ox = x0 + 4 * tl;
+    const int oy = y0 + 4 * (tl / TC), ox = x0 + 4 * (tl % TC);
     __amdgpu_buffer_rsrc_t rg = ru, ry = ru, ryp = ru, ryi = ru, rt = ru;
     if (GATE >= 1) rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.gate + (size_t)n * a.Cout * HW), 0, out_bytes, 0x00020000);
     if (a.y) ry = __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)n * a.Cout * HW, 0, out_bytes, 0x00020000);
@@ -352,8 +364,8 @@ __device__ __forceinline__ void wino43_body(const Wino43Args &a, float *smem) {
     f32x4 gq[GATE >= 1 ? 4 : 1];
     auto request = [&](int h) __attribute__((always_inline)) {
         const int col = 32 * h + col_l;
-        const bool inb = reader && y0 < H && ox < W;   // H % 4 == 0, W % 64 == 0: every reader (kept for the descriptor sentinel)
-        vo = inb ? (unsigned)((((size_t)co0 + col) * HW + (size_t)y0 * W + ox) * 4) : kOob;
+        const bool inb = reader && oy < H && ox < W;   // H, W multiples of the step: every reader (kept for the descriptor sentinel)
+        vo = inb ? (unsigned)((((size_t)co0 + col) * HW + (size_t)oy * W + ox) * 4) : kOob;
 #if defined(ST3D_W43_DIAG) && ST3D_W43_DIAG == 4       // diagnostic build: gate reads and output stores out of range (issued, no memory traffic)
         if (a.N >= 0) vo = kOob;
 #endif
@@ -509,11 +521,11 @@ __device__ __forceinline__ void wino43_body(const Wino43Args &a, float *smem) {
     }
 }
 
-template <int MODE, int EPI, int GATE>
+template <int MODE, int EPI, int GATE, int TC>
 __global__ __launch_bounds__(NT6, 3) void wino43_kernel(const Wino43Args a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) wino43_body<MODE, EPI, GATE, 1>(a, smem);
-    else wino43_body<MODE, EPI, GATE, 0>(a, smem);
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) wino43_body<MODE, EPI, GATE, 1, TC>(a, smem);
+    else wino43_body<MODE, EPI, GATE, 0, TC>(a, smem);
 }
 
 // w (Cout,Cin,3,3) -> U = G g G^T (6x6, fp64 -> fp32), forward and transposed (180-degree rotated filter, channel roles
@@ -552,16 +564,23 @@ __global__ void wino43_pack_kernel(const float *__restrict__ w, int Cout, int Ci
     }
 }
 
+// tiles across per workgroup step (Geo43): 16 where the row is a multiple of 64 pixels, else 8 for multiples of 32; 0 = not covered
+int tc43(int H, int W) {
+    if (H > 0 && W > 0 && (H % 4) == 0 && (W % 64) == 0) return 16;
+    if (H > 0 && W > 0 && (H % 8) == 0 && (W % 32) == 0) return 8;
+    return 0;
+}
 bool shape_ok43(int Cin, int Cout, int H, int W) {
-    return Cin >= 4 * KS6 && (Cin % KS6) == 0 && (Cout % 64) == 0 && (H % 4) == 0 && (W % 64) == 0 && H > 0 && W > 0 &&
+    return Cin >= 4 * KS6 && (Cin % KS6) == 0 && (Cout % 64) == 0 && tc43(H, W) != 0 &&
            (unsigned long long)Cin * (unsigned long long)H * (unsigned long long)W * 4ull < (1ull << 31) &&
            (unsigned long long)Cout * (unsigned long long)H * (unsigned long long)W * 4ull < (1ull << 31);
 }
 
-template <int MODE>
-int launch_wino43(Wino43Args a, hipStream_t s) {
-    a.tiles_x = a.W / T6_COLS;
-    a.tiles_y = a.H / T6_ROWS;
+template <int MODE, int TC>
+int launch_wino43_tc(Wino43Args a, hipStream_t s) {
+    using G = Geo43<TC>;
+    a.tiles_x = a.W / G::COLS;
+    a.tiles_y = a.H / G::ROWS;
     a.n_ct = a.Cout / 64;
     a.magic_x = (unsigned)((1ull << 32) / (unsigned)a.tiles_x + 1ull);      // (tiles_x == 1: unused)
     a.magic_y = (unsigned)((1ull << 32) / (unsigned)a.tiles_y + 1ull);
@@ -576,7 +595,7 @@ int launch_wino43(Wino43Args a, hipStream_t s) {
     if (const char *e = getenv("ST3D_W43_SLOTS")) nslots = atol(e);       // lab: 0 = one workgroup per tile
     if (nslots < 1 || nslots > npix) nslots = npix;
     const long blocks = (long)a.n_ct * nslots;
-    constexpr size_t kSmem = (size_t)SMEM6 * sizeof(float);       // dynamic LDS above the 64 KB static limit: opt in once per instantiation
+    constexpr size_t kSmem = (size_t)G::SMEM * sizeof(float);     // dynamic LDS above the 64 KB static limit: opt in once per instantiation
     auto go = [&](auto kernel) -> int {
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmem);
         if (attr != hipSuccess) { st3d::set_error("wino43: hipFuncSetAttribute(MaxDynamicSharedMemorySize): %s", hipGetErrorString(attr)); return ST3D_E_HIP; }
@@ -586,14 +605,19 @@ int launch_wino43(Wino43Args a, hipStream_t s) {
     };
     if (a.yp) {
         if (MODE != 0 || a.gate) { st3d::set_error("wino43: the fused pool belongs to the plain forward"); return ST3D_E_INVALID; }
-        return go(wino43_kernel<0, 1, 0>);
+        return go(wino43_kernel<0, 1, 0, TC>);
     }
     if (a.gate && a.addt) {
         if (MODE != 0) { st3d::set_error("wino43: the content-target term rides on ungated input (MODE 0) only"); return ST3D_E_INVALID; }
-        return go(wino43_kernel<0, 0, 2>);
+        return go(wino43_kernel<0, 0, 2, TC>);
     }
-    if (a.gate) return go(wino43_kernel<MODE, 0, 1>);
-    return go(wino43_kernel<MODE, 0, 0>);
+    if (a.gate) return go(wino43_kernel<MODE, 0, 1, TC>);
+    return go(wino43_kernel<MODE, 0, 0, TC>);
+}
+
+template <int MODE>
+int launch_wino43(Wino43Args a, hipStream_t s) {
+    return tc43(a.H, a.W) == 16 ? launch_wino43_tc<MODE, 16>(a, s) : launch_wino43_tc<MODE, 8>(a, s);
 }
 
 }  // namespace

@@ -540,8 +540,10 @@ def main():
                 "unit": "TFLOP/s", "frac": round(f_conv_issued / (kms * 1e-3) / PEAK_FP32_MFMA, 4),
                 "traffic": ktraffic, "traffic_source": tsrc if ktraffic else None,
                 "alg_equiv_tflops": round(f_conv_alg / (kms * 1e-3) / 1e12, 3),
-                "kernel": ("wino43_kernel (csrc/wino43.hip, F(4x4,3x3): %d launches) + wino4_kernel (csrc/wino.hip, F(2x2,3x3): %d launches)"
-                           % (n43, kn - n43)) if wino else "conv3x3_kernel (csrc/conv.hip)",
+                "kernel": (("wino43_kernel (csrc/wino43.hip, F(4x4,3x3): %d launches)" % n43 if n43 else "")
+                           + (" + " if n43 and kn > n43 else "")
+                           + ("wino4_kernel (csrc/wino.hip, F(2x2,3x3): %d launches)" % (kn - n43) if kn > n43 else ""))
+                          if wino else "conv3x3_kernel (csrc/conv.hip)",
                 "launches_per_step": kn, "avg_launch_ms": round(kms / kn, 4), "ms_per_step": round(kms, 4),
                 "share_of_step": round(kms / (dev_ms / args.steps), 4),
                 "flops_per_launch_issued": round(f_conv_issued / kn), "flops_per_launch_alg": round(f_conv_alg / kn),

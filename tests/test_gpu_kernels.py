@@ -538,7 +538,9 @@ def test_wino_fused_pool_and_unpool(dev, ops, N, Cin, Cout, H, W):
 
 # ---------------------------------------------------------------------------- Winograd F(4x4,3x3) conv (round 3)
 @pytest.mark.parametrize("N,Cin,Cout,H,W", [(1, 64, 64, 4, 64), (2, 128, 64, 8, 64), (1, 256, 256, 16, 128), (1, 512, 512, 64, 64),
-                                             (2, 128, 256, 12, 192)])
+                                             (2, 128, 256, 12, 192),
+                                             # 8 x 32-pixel workgroup steps (W % 32 == 0, H % 8 == 0): conv5_1 at 512^2, a 96-wide map
+                                             (2, 512, 512, 32, 32), (2, 64, 128, 16, 96), (1, 128, 64, 8, 32)])
 @pytest.mark.parametrize("slots", ["", "1", "4"])
 def test_wino43_fwd_and_chain_dgrad(dev, ops, monkeypatch, N, Cin, Cout, H, W, slots):
     """F(4x4,3x3) kernel (csrc/wino43.hip) against an fp64 direct convolution at the SAME tolerance as the F(2x2,3x3)
@@ -592,7 +594,8 @@ def test_wino43_fwd_and_chain_dgrad(dev, ops, monkeypatch, N, Cin, Cout, H, W, s
     assert torch.equal(ops.wino43_dgrad_chain(gp, ud, Cin, pool_idx=pidx, out_gate=og),
                        ops.wino43_dgrad_chain(up, ud, Cin, out_gate=og))
     # shapes outside the tiling are refused, not mis-computed
-    assert ops._lib.load().st3d_wino43_supported(Cin, Cout, H, W + 32) == 0 and ops._lib.load().st3d_wino43_supported(48, Cout, H, W) == 0
+    assert ops._lib.load().st3d_wino43_supported(Cin, Cout, H, W + 16) == 0 and ops._lib.load().st3d_wino43_supported(48, Cout, H, W) == 0
+    assert ops._lib.load().st3d_wino43_supported(Cin, Cout, 12, 96) == 0         # 32-pixel rows need H % 8 == 0
 
 
 # ---------------------------------------------------------------------------- general soft renderer (K faces / pixel, blur)

@@ -79,14 +79,14 @@ def main():
                               "duration_ms_under_pmc": round(ns * 1e-6, 4)}
     w4, w6 = out["families"].get("wino4_kernel"), out["families"].get("wino43_kernel")
     if w4 or w6:
-        # the default plan at 8 x 512^2: F(4x4,3x3) (36/144 of the direct count) where Cin >= 64 and W % 64 == 0 -- conv1_2 ..
-        # conv4_4 -- and F(2x2,3x3) (16/36) for conv5_1 (W = 32); forward + input gradient each.  Without the wino43 family in
+        # the default plan at 8 x 512^2: F(4x4,3x3) (36/144 of the direct count) where Cin >= 64 and W % 32 == 0 -- conv1_2 ..
+        # conv5_1 -- and F(2x2,3x3) (16/36) for whatever is left; forward + input gradient each.  Without the wino43 family in
         # the trace (ST3D_WINO43=0) every layer is priced as F(2x2,3x3).
         S, B = 512, 8
         convs = [(64, 64, 1), (64, 128, 2), (128, 128, 2), (128, 256, 4), (256, 256, 4), (256, 256, 4), (256, 256, 4), (256, 512, 8),
                  (512, 512, 8), (512, 512, 8), (512, 512, 8), (512, 512, 16)]
         direct = lambda ci, co, d: 2.0 * 9 * ci * co * (S // d) ** 2 * B
-        on43 = lambda ci, co, d: w6 is not None and ci >= 64 and (S // d) % 64 == 0
+        on43 = lambda ci, co, d: w6 is not None and ci >= 64 and ((S // d) % 64 == 0 or (S // d) % 32 == 0)
         a4 = sum(direct(*c) for c in convs if not on43(*c)) * 2 * 16.0 / 36.0
         a6 = sum(direct(*c) for c in convs if on43(*c)) * 2 * 36.0 / 144.0
         for w, an in ((w4, a4), (w6, a6)):

@@ -14,7 +14,7 @@ dev = torch.device("cuda:0")
 # (name, Cin, Cout, divisor, pooled_after, grad_arrives_pooled)
 LAYERS = [("conv1_2", 64, 64, 1, True, True), ("conv2_1", 64, 128, 2, False, False), ("conv2_2", 128, 128, 2, True, True), ("conv3_1", 128, 256, 4, False, False), ("conv3_2", 256, 256, 4, False, False),
           ("conv3_4", 256, 256, 4, True, True), ("conv4_1", 256, 512, 8, False, False), ("conv4_2", 512, 512, 8, False, False),
-          ("conv4_4", 512, 512, 8, True, True)]
+          ("conv4_4", 512, 512, 8, True, True), ("conv5_1", 512, 512, 16, False, False)]
 def timeit(fn, n=10):
     for _ in range(2): fn()
     torch.cuda.synchronize()
