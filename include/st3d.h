@@ -256,7 +256,8 @@ int st3d_wino_dgrad_chain(const float *gy, const float *act, const uint8_t *pool
                           float *gx, int N, int Cin, int Cout, int H, int W, st3d_stream_t stream);
 /* The same convolutions as Winograd F(4x4,3x3) (csrc/wino43.hip, round 3): 2.25 instead of 4 MFMA-multiplies per output
  * pixel, fp32 throughout (<= 1.3e-5 of the output scale against an fp64 convolution at K = 512).  Shapes: Cin >= 64,
- * Cin % 16 == 0, Cout % 64 == 0 (both % 64 for the pack), H % 4 == 0, W % 64 == 0, each tensor < 2^31 bytes per image
+ * Cin % 16 == 0, Cout % 64 == 0 (both % 64 for the pack), and H % 4 == 0 with W % 64 == 0 or H % 8 == 0 with W % 32 == 0
+ * (the workgroup's step is 4 x 64 or 8 x 32 pixels), each tensor < 2^31 bytes per image
  * (st3d_wino43_supported).  Own filter pack (36 floats per weight).  One persistent workgroup per CU.
  * st3d_wino43_dgrad_chain takes an already gated gradient (or, with pool_idx, the pooled-resolution gradient) exactly as
  * st3d_wino_dgrad_chain does with act == pooled == NULL. */
