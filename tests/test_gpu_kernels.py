@@ -997,6 +997,22 @@ def test_wino_32bit_offset_guard_and_large_images(dev, ops):
     # above the guard the entry points refuse loudly instead of reading garbage
     with pytest.raises(_lib.St3dError):
         ops.wino_fwd(torch.empty((1, 64, 2900, 2900), device=dev), uf, None, C)
+    # the same for the F(4x4,3x3) kernel (what the plan runs at this size): guard, then the 1 GiB operands
+    assert lib.st3d_wino43_supported(64, 64, 2048, 2048) == 1 and lib.st3d_wino43_supported(64, 64, 2880, 2880) == 1
+    assert lib.st3d_wino43_supported(64, 64, 2944, 2944) == 0 and lib.st3d_wino43_supported(128, 128, 2048, 2048) == 0
+    u6f, u6d = ops.wino43_pack(w.to(dev))
+    y = ops.wino43_fwd(x, u6f, b.to(dev), C, relu=False)
+    gx = ops.wino43_dgrad_chain(x, u6d, C)
+    for y0, x0 in ((0, 0), (0, S - h), (S - h, 0), (S - h, S - h), (1000, 1004), (S - h, 900)):
+        ref = _crop_ref(x, y0, x0, h, 1, fwd)
+        got = y[:, :, y0:y0 + h, x0:x0 + h].cpu().double()
+        assert float((got - ref).abs().max()) <= 3e-5 * float(ref.abs().max()), (y0, x0)
+        refg = _crop_ref(x, y0, x0, h, 1, bwd)
+        gotg = gx[:, :, y0:y0 + h, x0:x0 + h].cpu().double()
+        assert float((gotg - refg).abs().max()) <= 5e-5 * float(refg.abs().max()), (y0, x0)
+    del y, gx
+    with pytest.raises(_lib.St3dError):
+        ops.wino43_fwd(torch.empty((1, 64, 2944, 2944), device=dev), u6f, None, C)
 
 
 def test_plan_falls_back_to_direct_kernels_above_the_wino_guard(dev):
