@@ -70,7 +70,7 @@ constexpr int NT6 = 768;                 // 12 waves
 struct Wino43Args {
     const float *x;       // MODE 0: (N,Cin,H,W); MODE 3: pooled-resolution gradient (N,Cin,H/2,W/2), already gated
     const uint8_t *idx;   // MODE 3: pool argmax
-    const float *U;       // packed [ct][kstep][wave 12][lane 64][12]  (wino43_pack_kernel)
+    const float *U;       // packed [ct][kstep][wave 12][b 3][lane 64][cb 4]  (wino43_pack_kernel)
     const float *bias;    // (Cout) or nullptr
     float *y;             // (N,Cout,H,W) or nullptr (EPI 1 may skip the full-resolution store)
     float *yp;            // EPI 1: pooled output (N,Cout,H/2,W/2)
@@ -180,7 +180,7 @@ __device__ __forceinline__ void wino43_body(const Wino43Args &a, float *smem) {
     const int nksteps = a.Cin / 4;
     const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(a.U + (size_t)ct * nksteps * (12 * 64 * 12)), 0, (unsigned)((size_t)nksteps * 12 * 64 * 12 * 4), 0x00020000);
-    const unsigned uvoff = (unsigned)((wave * 64 + lane) * 48);
+    const unsigned uvoff = (unsigned)(wave * 3072 + lane * 16);
 
     struct Staged { f32x2 v[UNPOOL ? 1 : 6]; float g[UNPOOL ? 6 : 1]; unsigned i[UNPOOL ? 6 : 1]; };
     auto gload = [&](int st, Staged &x) __attribute__((always_inline)) {
@@ -249,7 +249,7 @@ __device__ __forceinline__ void wino43_body(const Wino43Args &a, float *smem) {
         const unsigned so = (unsigned)min(kstep, nksteps - 1) * (unsigned)(12 * 64 * 12 * 4);
 #endif
 #pragma unroll
-        for (int b = 0; b < 3; ++b) u.q[b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, uvoff + 16 * b, so, 0));
+        for (int b = 0; b < 3; ++b) u.q[b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, uvoff + 1024 * b, so, 0));
     };
 
     f32x4 acc[3][4];       // [b][cout block]
@@ -266,7 +266,8 @@ __device__ __forceinline__ void wino43_body(const Wino43Args &a, float *smem) {
     // k-step instead of behind the MFMAs 7.08.  With the loads out of range (no memory traffic) the sum is 6.1, with no
     // staging at all 5.8: the round trip of the patch rows is worth 10 % (20 % at conv1_2, whose input comes from HBM).
     // Workgroups of different slots started a fraction of a stage apart (so that the CUs do not all request in the same
-    // microsecond): no change at any delay.
+    // microsecond): no change at any delay.  Filter operands FOUR k-steps ahead (into the set just consumed): 6.65 against
+    // 6.42 -- more requests in flight make it worse, not better.
     Staged xs;
     // ---- prologue (once per workgroup): stages 0 and 1 of its first tile, both requests in flight together
     {
@@ -530,13 +531,15 @@ __global__ __launch_bounds__(NT6, 3) void wino43_kernel(const Wino43Args a) {
 
 // w (Cout,Cin,3,3) -> U = G g G^T (6x6, fp64 -> fp32), forward and transposed (180-degree rotated filter, channel roles
 // swapped), in the A-operand order of wino43_kernel for GEMM (M = out channel m, K = in channel k):
-//   [ct = m/64][kstep = k/4][wave = 2 a + bh][lane = (m%16) + 16 (k%4)][bi*4 + cb]   with b = 3 bh + bi, cb = (m%64)/16
+//   [ct = m/64][kstep = k/4][wave = 2 a + bh][bi][lane = (m%16) + 16 (k%4)][cb]   with b = 3 bh + bi, cb = (m%64)/16
 __device__ __forceinline__ size_t upack43_index(int m, int k, int aa, int bb, int K) {
     const int ct = m >> 6, col = m & 63, cb = col >> 4, m16 = col & 15;
     const int kstep = k >> 2, kq = k & 3;
     const int wave = 2 * aa + (bb >= 3 ? 1 : 0), bi = bb % 3;
     const int lane = m16 + 16 * kq;
-    return ((((size_t)ct * (K >> 2) + kstep) * 12 + wave) * 64 + lane) * 12 + bi * 4 + cb;
+    // ([wave][bi][lane][cb]: every 16-byte operand load of a wave reads 1 KB of contiguous memory -- eight full cache lines;
+    //  with the lane's three b next to each other it touched all 24 lines of the 3 KB block, a third of each)
+    return (((((size_t)ct * (K >> 2) + kstep) * 12 + wave) * 3 + bi) * 64 + lane) * 4 + cb;
 }
 
 __global__ void wino43_pack_kernel(const float *__restrict__ w, int Cout, int Cin, float *__restrict__ uf, float *__restrict__ ud) {
