@@ -374,7 +374,7 @@ __device__ __forceinline__ void wino43_body(const Wino43Args &a, float *smem) {
         if (GATE >= 1) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                gq[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, W43_GATE_VO(vo), (unsigned)(i * W * 4), 0));
+                gq[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, W43_GATE_VO(vo), (unsigned)(i * W * 4), 2));
         }
     };
     request(0);
@@ -465,10 +465,13 @@ __device__ __forceinline__ void wino43_body(const Wino43Args &a, float *smem) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) rowv[i][j] = g[j] > 0.f ? rowv[i][j] : 0.f;
                 }
+                // Non-temporal stores (and gate reads, above): what a tile writes is read next by ANOTHER kernel, out of the
+                // memory-side cache at best -- kept out of L2 it leaves the XCD's 4 MB to the filter operands and the patch rows
+                // the cout tiles share (-2.6 % on the nine-layer sum; non-temporal PATCH loads, which lose that sharing: +12 %).
                 // (row offset in the VECTOR offset, scalar offset 0: with an SGPR scalar offset the compiler assumes the 16-byte
                 //  store has read its data registers at issue and reuses them for the next row at once -- on gfx950 the last
                 //  lanes of the store then picked up the next row's values now and then: rowv[1][0] came out as rowv[2][2])
-                if (a.y) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rowv[i]), ry, inb ? vo + (unsigned)(i * W * 4) : kOob, 0, 0);
+                if (a.y) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rowv[i]), ry, inb ? vo + (unsigned)(i * W * 4) : kOob, 0, 2);
             }
             if (EPI == 1) {     // MaxPool2d(2,2): first maximum in row-major window order (ATen); four windows per 4x4 tile
                 const unsigned vp = inb ? (unsigned)((((size_t)co0 + col) * HpWp + (size_t)(oy >> 1) * Wp + (ox >> 1)) * 4) : kOob;
@@ -485,8 +488,8 @@ __device__ __forceinline__ void wino43_body(const Wino43Args &a, float *smem) {
                         if (w11 > bv || w11 != w11) { bv = w11; bi = 3; }
                         best[pj] = bv; bidx |= (unsigned)(bi << (8 * pj));
                     }
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, best), ryp, vp, (unsigned)(pi * Wp * 4), 0);
-                    if (a.yidx) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)bidx, ryi, vp == kOob ? kOob : vp / 4, (unsigned)(pi * Wp), 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, best), ryp, vp, (unsigned)(pi * Wp * 4), 2);
+                    if (a.yidx) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)bidx, ryi, vp == kOob ? kOob : vp / 4, (unsigned)(pi * Wp), 2);
                 }
             }
         }
