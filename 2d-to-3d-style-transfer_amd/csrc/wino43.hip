@@ -79,6 +79,7 @@ struct Wino43Args {
     const float *gate;    // (N,Cout,H,W) or nullptr: outputs are zeroed where gate <= 0 (the consumer's ReLU gate, see wino.hip)
     const float *addt;    // with gate: outputs become gate > 0 ? y + addc * (gate - addt) : 0
     float addc;
+    int xpc;                        // XCDs per cout tile (slots are renumbered XCD-major, see wino43_body); 1 = as dealt
     unsigned magic_x, magic_y;      // floor(2^32 / tiles_x) + 1, likewise tiles_y: pix / tiles_x = umulhi(pix, magic_x) for pix * tiles_x < 2^32 (tiles_x >= 2)
 };
 
@@ -120,7 +121,14 @@ __device__ __forceinline__ void wino43_body(const Wino43Args &a, float *smem) {
     // so its filter operands are the same 36 x 64 x K slab for every tile and the stream of stages simply continues from one
     // tile into the next: the ring already holds the next tile's first two stages when a tile's last MFMA issues, the
     // operand requests wrap around, and only the output exchange stands between two tiles (no prologue, no relaunch).
-    const int ct = blockIdx.x % a.n_ct, slot = blockIdx.x / a.n_ct, nslots = gridDim.x / a.n_ct;
+    // XCD-MAJOR SLOTS.  Workgroups are dealt round-robin over the 8 XCDs, so with the slots in tile order each XCD gets every
+    // xpc-th tile of a row of tiles: horizontal neighbours, which share the 16-byte slivers at both ends of every 288-byte
+    // patch row (4 cache lines touched for 2.25 lines of data), sit in DIFFERENT L2s and both fetch both lines (measured:
+    // 1.5 - 1.8x the compulsory L2 miss traffic at conv1_2 .. conv3_x).  Renumbered, an XCD's slots of one round are a
+    // contiguous run of tiles -- whole rows of tiles, several deep: slivers and halo rows hit in its own L2.
+    const int ct = blockIdx.x % a.n_ct, nslots = gridDim.x / a.n_ct;
+    int slot = blockIdx.x / a.n_ct;
+    if (a.xpc > 1) slot = (slot % a.xpc) * (nslots / a.xpc) + slot / a.xpc;
     const int npix = a.tiles_x * a.tiles_y * a.N;
     const int co0 = ct * 64;
     int n = 0, x0 = 0, y0 = 0;                 // the tile whose patch columns are being STAGED (runs two stages ahead)
@@ -601,6 +609,9 @@ int launch_wino43_tc(Wino43Args a, hipStream_t s) {
     if (const char *e = getenv("ST3D_W43_SLOTS")) nslots = atol(e);       // lab: 0 = one workgroup per tile
     if (nslots < 1 || nslots > npix) nslots = npix;
     const long blocks = (long)a.n_ct * nslots;
+    a.xpc = 1;
+    if (a.n_ct <= 8 && 8 % a.n_ct == 0 && nslots % (8 / a.n_ct) == 0) a.xpc = 8 / a.n_ct;
+    if (const char *e = getenv("ST3D_W43_XCD")) { if (atoi(e) == 0) a.xpc = 1; }        // A/B: 0 = slots in tile order
     constexpr size_t kSmem = (size_t)G::SMEM * sizeof(float);     // dynamic LDS above the 64 KB static limit: opt in once per instantiation
     auto go = [&](auto kernel) -> int {
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmem);
