@@ -23,6 +23,7 @@
  *   ST3D_CONV=direct            direct implicit-GEMM convolutions (conv.hip) instead of Winograd
  *   ST3D_WINO43=0, ST3D_WINO43_MINK=k   never run the F(4x4,3x3) Winograd kernel (wino43.hip) / only from k input channels (default 64)
  *   ST3D_W43_SLOTS=n            persistent workgroups per cout tile of the F(4x4,3x3) kernel (default: CUs / cout tiles)
+ *   ST3D_W43_XCD=0              its slots in tile order instead of XCD-major
  *   ST3D_WINO_MAP=rr|xcd        block -> tile mapping of the F(2x2,3x3) Winograd launches
  *   ST3D_PREGATE=0              every input-gradient applies its own ReLU gate (consumer side)
  *   ST3D_TAP0_FUSED=0, ST3D_TAP0_J=1   separate relu1_1 Gram backward + conv1_1 input gradient / 4-byte accesses
