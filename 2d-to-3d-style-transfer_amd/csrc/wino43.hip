@@ -16,8 +16,9 @@
 //     the raw patch -- so a wave reads only ITS row a (6 floats per (tile, channel)) and does the column half for its
 //     three b (6-7 VALU).  That is the same ~1 vector-ALU instruction per 64 MFMA cycles in the waves' loop as
 //     wino4_kernel has, for 2.25 instead of 4 MFMA-multiplies per output.
-//   * A operands U = G g G^T (fp64 -> fp32, packed per lane: 12 contiguous floats per 4-channel k-step) come straight from
-//     L2 through a buffer descriptor, three k-steps ahead; they never touch LDS.
+//   * A operands U = G g G^T (fp64 -> fp32, packed [wave][b][lane][4 cout blocks] per 4-channel k-step: three 16-byte loads
+//     per lane, each 1 KB contiguous per wave) come straight from L2 through a buffer descriptor, three k-steps ahead; they
+//     never touch LDS.
 //   * Staging: 16 channels per stage, 3-deep ring, one barrier per stage.  A half-item = (channel, column pair): six row
 //     loads -> gate (MODE) -> row transform of both columns in packed fp32 math -> six 8-byte LDS stores.  576 half-items
 //     per stage on 768 threads: every wave stages the same amount every stage, interleaved with its MFMAs -- with one
@@ -26,10 +27,11 @@
 //   * PERSISTENT workgroups, one per CU: workgroup (cout tile, slot) walks the pixel tiles slot, slot + nslots, ...; the
 //     stream of stages runs on from one tile into the next (the ring holds the next tile's first two stages when a tile's
 //     last MFMA issues), the exchange region is separate from the ring, and only the epilogue stands between two tiles.
-//   * Epilogue: along b in registers (partial over the wave's three b), then per output column j one LDS exchange
-//     [6 a][64 co][16 tiles][2 bh]; a reader owns whole 4x4 output tiles (two per thread of the first 8 waves), so the
-//     2x2 max-pool (+argmax), ReLU, the producer-side gates of the backward chain and 16-byte row stores all happen in
-//     registers, as in wino4_kernel.
+//   * Epilogue: along b in registers (partial over the wave's three b), then four LDS exchange passes = (cout half) x
+//     (output-column pair) through [6 a][32 co][16 tiles][2 bh][2 columns], packed fp32 math on both sides; a reader (the
+//     first 8 waves) owns one whole 4x4 output tile per half, so the 2x2 max-pool (+argmax), ReLU, the producer-side gates
+//     of the backward chain and 16-byte row stores all happen in registers, as in wino4_kernel.  Outputs and gate reads are
+//     non-temporal; slots are numbered XCD-major (see wino43_body).
 #include <stdlib.h>
 #include <string.h>
 
