@@ -72,3 +72,23 @@ def test_product_path_refuses_cpu_tensors(lib_path):
     import style_transfer as ST
     with pytest.raises(RuntimeError):
         ST.gram_matrix(torch.rand(1, 4, 2, 2))
+
+
+def test_winograd_shape_guards_are_pure_host_logic(lib_path):
+    """st3d_wino_supported / st3d_wino43_supported / st3d_wino43_packed_floats touch no device: the tiling rules of
+    include/st3d.h hold on a box without a GPU (F(4x4,3x3): Cin >= 64 in steps of 16, Cout in steps of 64, rows of a multiple
+    of 64 pixels with H % 4 == 0 or of 32 pixels with H % 8 == 0, each tensor below 2^31 bytes per image)."""
+    lib = ctypes.CDLL(lib_path)
+    ok43 = lambda *a: lib.st3d_wino43_supported(*a)
+    # the twelve Winograd layers of VGG-19 at 512^2: all on F(4x4,3x3)
+    for cin, cout, d in ((64, 64, 1), (64, 128, 2), (128, 128, 2), (128, 256, 4), (256, 256, 4), (256, 512, 8), (512, 512, 8),
+                         (512, 512, 16)):
+        assert ok43(cin, cout, 512 // d, 512 // d) == 1, (cin, cout, d)
+    # the reference's default 768^2: conv4_x (96 wide) yes, conv5_1 (48 wide) no
+    assert ok43(256, 512, 96, 96) == 1 and ok43(512, 512, 48, 48) == 0
+    assert ok43(3, 64, 512, 512) == 0 and ok43(48, 64, 64, 64) == 0 and ok43(64, 32, 64, 64) == 0 and ok43(72, 64, 64, 64) == 0
+    assert ok43(64, 64, 12, 96) == 0 and ok43(64, 64, 16, 96) == 1 and ok43(64, 64, 6, 64) == 0 and ok43(64, 64, 4, 64) == 1
+    assert ok43(64, 64, 2880, 2880) == 1 and ok43(64, 64, 2944, 2944) == 0 and ok43(128, 128, 2048, 2048) == 0
+    lib.st3d_wino43_packed_floats.restype = ctypes.c_size_t
+    assert lib.st3d_wino43_packed_floats(512, 256) == 36 * 512 * 256
+    assert lib.st3d_wino_supported(512, 512, 48, 48) == 1          # what the plan falls back to there
