@@ -540,6 +540,9 @@ def main():
                 "unit": "TFLOP/s", "frac": round(f_conv_issued / (kms * 1e-3) / PEAK_FP32_MFMA, 4),
                 "traffic": ktraffic, "traffic_source": tsrc if ktraffic else None,
                 "alg_equiv_tflops": round(f_conv_alg / (kms * 1e-3) / 1e12, 3),
+                # the number earlier rounds reported as `frac`, when every launch was F(2x2,3x3): 16/36 of the direct count
+                # over the same time / peak.  Above 1 once launches run F(4x4,3x3) -- a comparison across rounds, not a roofline
+                "f23_equiv_of_peak": round(f_conv_alg * 16.0 / 36.0 / (kms * 1e-3) / PEAK_FP32_MFMA, 4),
                 "kernel": (("wino43_kernel (csrc/wino43.hip, F(4x4,3x3): %d launches)" % n43 if n43 else "")
                            + (" + " if n43 and kn > n43 else "")
                            + ("wino4_kernel (csrc/wino.hip, F(2x2,3x3): %d launches)" % (kn - n43) if kn > n43 else ""))
@@ -553,7 +556,8 @@ def main():
                         "input-gradient of every VGG conv but conv1_1: %.1f GF issued, %.1f GF algorithmic per step) / their "
                         "HIP-event time on the launch stream over %d steps after the timed region; frac = matrix-pipe "
                         "utilisation.  alg_equiv_tflops = the direct-convolution count over the same time (may exceed the "
-                        "peak; it is not a roofline fraction)." % (f_conv_issued / 1e9, f_conv_alg / 1e9, nprof)}
+                        "peak; it is not a roofline fraction); f23_equiv_of_peak = the round-1/2 `frac` metric (every launch "
+                        "priced as F(2x2,3x3)) for comparison across rounds." % (f_conv_issued / 1e9, f_conv_alg / 1e9, nprof)}
         if args.approach == "first_b" and kernels:
             # phase B of the first approach has no VGG: the step IS the HBM/latency-bound render + scatter kernels.  Its
             # roofline is HBM: algorithmic bytes of SURVEY.md 8d per kernel over the kernel's own (standalone, back-to-back)
