@@ -487,49 +487,72 @@ struct ReduceMulti { ReduceItem r[kMaxGramItems]; int first[kMaxGramItems + 1]; 
 // over its slabs in ascending order, then ((p0+p1)+(p2+p3))) -- bitwise reproducible, and four times the loads in
 // flight of a single running sum.  Only tiles on/above the diagonal are read (coalesced); each such element is also
 // written to its mirror position, so the Gram is exactly symmetric.
+// VW consecutive elements of a row per thread (VW = 4: 16-byte loads of the slabs, a quarter of the workgroups; C and TM
+// multiples of 4) -- every element keeps its own tree, so the result does not depend on VW.
+template <int VW>
 __device__ __forceinline__ void gram_reduce_body(const float *__restrict__ slab, int nsplit, int C, int TM, size_t sSplit,
                                                  size_t sB, float *__restrict__ gram, const int bx, const int by,
-                                                 float (*part)[64]) {
+                                                 float (*part)[64 * VW]) {
+    typedef float vec __attribute__((ext_vector_type(VW)));
     const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const size_t i = (size_t)bx * 64 + e;
+    const size_t i = ((size_t)bx * 64 + e) * VW;
     const size_t CC = (size_t)C * C;
     const int b = by;
-    float s = 0.f;
+    float s[VW];
+#pragma unroll
+    for (int j = 0; j < VW; ++j) s[j] = 0.f;
     const int r = (i < CC) ? (int)(i / C) : 0, c = (i < CC) ? (int)(i % C) : 0;
     const bool lower = r / TM > c / TM;         // tile below the diagonal: written by its mirror image's threads
     if (i < CC && !lower) {
         const float *p = slab + b * sB + (size_t)r * C + c;
+        auto ld = [&](int k) __attribute__((always_inline)) { return *reinterpret_cast<const vec *>(p + k * sSplit); };
         int k = q;
         for (; k + 12 < nsplit; k += 16) {
-            const float a0 = p[k * sSplit], a1 = p[(k + 4) * sSplit], a2 = p[(k + 8) * sSplit], a3 = p[(k + 12) * sSplit];
-            s += a0; s += a1; s += a2; s += a3;
+            const vec a0 = ld(k), a1 = ld(k + 4), a2 = ld(k + 8), a3 = ld(k + 12);
+#pragma unroll
+            for (int j = 0; j < VW; ++j) { s[j] += a0[j]; s[j] += a1[j]; s[j] += a2[j]; s[j] += a3[j]; }
         }
-        for (; k < nsplit; k += 4) s += p[k * sSplit];
+        for (; k < nsplit; k += 4) {
+            const vec a0 = ld(k);
+#pragma unroll
+            for (int j = 0; j < VW; ++j) s[j] += a0[j];
+        }
     }
-    part[q][e] = s;
+#pragma unroll
+    for (int j = 0; j < VW; ++j) part[q][e * VW + j] = s[j];
     __syncthreads();
     if (q == 0 && i < CC && !lower) {
-        const float v = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
-        gram[b * CC + i] = v;
-        if (r / TM < c / TM) gram[b * CC + (size_t)c * C + r] = v;       // the mirrored (never computed) tile
+        vec v;
+#pragma unroll
+        for (int j = 0; j < VW; ++j) v[j] = (part[0][e * VW + j] + part[1][e * VW + j]) + (part[2][e * VW + j] + part[3][e * VW + j]);
+        *reinterpret_cast<vec *>(gram + b * CC + i) = v;
+        if (r / TM < c / TM) {                                               // the mirrored (never computed) tile
+#pragma unroll
+            for (int j = 0; j < VW; ++j) gram[b * CC + (size_t)(c + j) * C + r] = v[j];
+        }
     }
 }
 
+template <int VW>
 __global__ __launch_bounds__(256) void gram_reduce_kernel(const float *__restrict__ slab, int nsplit, int C, int TM,
                                                           size_t sSplit, size_t sB, float *__restrict__ gram) {
-    __shared__ float part[4][64];
-    gram_reduce_body(slab, nsplit, C, TM, sSplit, sB, gram, blockIdx.x, blockIdx.y, part);
+    __shared__ float part[4][64 * VW];
+    gram_reduce_body<VW>(slab, nsplit, C, TM, sSplit, sB, gram, blockIdx.x, blockIdx.y, part);
 }
 
 // the slab reductions of all layers in one launch (same fixed tree per element as gram_reduce_kernel)
+template <int VW>
 __global__ __launch_bounds__(256) void gram_reduce_multi_kernel(const ReduceMulti m) {
-    __shared__ float part[4][64];
+    __shared__ float part[4][64 * VW];
     int b = blockIdx.x, it = 0;
     while (it + 1 < m.n_items && b >= m.first[it + 1]) ++it;
     b -= m.first[it];
     const ReduceItem &r = m.r[it];
-    gram_reduce_body(r.slab, r.nsplit, r.C, r.TM, r.sSplit, r.sB, r.gram, b % r.blocks_per_image, b / r.blocks_per_image, part);
+    gram_reduce_body<VW>(r.slab, r.nsplit, r.C, r.TM, r.sSplit, r.sB, r.gram, b % r.blocks_per_image, b / r.blocks_per_image, part);
 }
+
+// 16-byte slab reads need C (row length, slab strides) and the tile height in multiples of 4
+inline int gram_reduce_vw(int C, int TM, size_t sSplit, size_t sB) { return (C % 4 == 0 && TM % 4 == 0 && sSplit % 4 == 0 && sB % 4 == 0) ? 4 : 1; }
 
 // K split: enough workgroups to fill the chip a few times over (256 CUs x 2 resident workgroups x 1..4), but
 // at least 8 K-chunks of work per workgroup and at most 256 slabs.
@@ -627,7 +650,10 @@ extern "C" int st3d_gram_fwd(const float *feat, int B, int C, int HW, void *work
         if (C == 64) gram_diag_kernel<2><<<dim3(1, g.nsplit, B), 256, 0, s>>>(g);
         else gram_diag_kernel<4><<<dim3(1, g.nsplit, B), 256, 0, s>>>(g);
         ST3D_LAUNCH_CHECK();
-        gram_reduce_kernel<<<dim3(st3d::cdiv((long)C * C, 64), B), 256, 0, s>>>(g.C, q.red_nsplit, C, q.red_tm, g.sSplit, g.sC, gram);
+        if (gram_reduce_vw(C, q.red_tm, g.sSplit, g.sC) == 4)
+            gram_reduce_kernel<4><<<dim3(st3d::cdiv((long)C * C, 256), B), 256, 0, s>>>(g.C, q.red_nsplit, C, q.red_tm, g.sSplit, g.sC, gram);
+        else
+            gram_reduce_kernel<1><<<dim3(st3d::cdiv((long)C * C, 64), B), 256, 0, s>>>(g.C, q.red_nsplit, C, q.red_tm, g.sSplit, g.sC, gram);
         ST3D_LAUNCH_CHECK();
         return ST3D_OK;
     }
@@ -637,7 +663,10 @@ extern "C" int st3d_gram_fwd(const float *feat, int B, int C, int HW, void *work
     } else if (TM == 128) { if (fast) gemm_kernel<2, 2, 0, 0, 32, true><<<grid, 256, 0, s>>>(g); else gemm_kernel<2, 2, 0><<<grid, 256, 0, s>>>(g); }
     else gemm_kernel<1, 1, 0><<<grid, 256, 0, s>>>(g);
     ST3D_LAUNCH_CHECK();
-    gram_reduce_kernel<<<dim3(st3d::cdiv((long)C * C, 64), B), 256, 0, s>>>(g.C, q.red_nsplit, C, q.red_tm, g.sSplit, g.sC, gram);
+    if (gram_reduce_vw(C, q.red_tm, g.sSplit, g.sC) == 4)
+            gram_reduce_kernel<4><<<dim3(st3d::cdiv((long)C * C, 256), B), 256, 0, s>>>(g.C, q.red_nsplit, C, q.red_tm, g.sSplit, g.sC, gram);
+        else
+            gram_reduce_kernel<1><<<dim3(st3d::cdiv((long)C * C, 64), B), 256, 0, s>>>(g.C, q.red_nsplit, C, q.red_tm, g.sSplit, g.sC, gram);
     ST3D_LAUNCH_CHECK();
     return ST3D_OK;
 }
@@ -717,17 +746,22 @@ extern "C" int st3d_gram_fwd_multi(const st3d_gram_item *items, int count, void 
         if (restblocks == 0) gm.stride = gm.n0 > 0 ? 1 : 0;
         gram_multi_kernel<<<total, 256, 0, s>>>(gm);
         ST3D_LAUNCH_CHECK();
-        int rblocks = 0;
+        int rblocks = 0, vw = 4;
+        for (int k = 0; k < nf; ++k) {
+            const GramFwdPlan &q = plans[order[k]];
+            if (gram_reduce_vw(items[order[k]].C, q.red_tm, q.g.sSplit, q.g.sC) != 4) vw = 1;
+        }
         for (int k = 0; k < nf; ++k) {
             const int i = order[k];
             const GramFwdPlan &q = plans[i];
-            const int bpi = (int)st3d::cdiv((long)items[i].C * items[i].C, 64);
+            const int bpi = (int)st3d::cdiv((long)items[i].C * items[i].C, 64 * vw);
             rm.r[k] = ReduceItem{q.g.C, items[i].gram, q.red_nsplit, items[i].C, q.red_tm, bpi, q.g.sSplit, q.g.sC};
             rm.first[k] = rblocks;
             rblocks += bpi * items[i].B;
         }
         rm.first[nf] = rblocks; rm.n_items = nf;
-        gram_reduce_multi_kernel<<<rblocks, 256, 0, s>>>(rm);
+        if (vw == 4) gram_reduce_multi_kernel<4><<<rblocks, 256, 0, s>>>(rm);
+        else gram_reduce_multi_kernel<1><<<rblocks, 256, 0, s>>>(rm);
         ST3D_LAUNCH_CHECK();
     }
     for (int i = 0; i < count; ++i)
