@@ -88,7 +88,7 @@ struct Wino43Args {
 // T_a = sum_r B^T[a][r] d[r] for a = 0..5 (and, applied to t0..t5, the column half V_b = sum_c B^T[b][c] t[c])
 //   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
 // (T = f32x2: two patch columns at once in packed fp32 math -- v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32: 14 instructions
-//  for both columns; every non-MFMA instruction of the stage loop is exposed next to the fp32 MFMAs)
+//  for both columns; the fp32 MFMA does not co-execute with the vector ALU)
 template <typename T>
 __device__ __forceinline__ void bt6(T d0, T d1, T d2, T d3, T d4, T d5, T &t0, T &t1, T &t2, T &t3, T &t4, T &t5) {
     const T p = d4 - 4.f * d2, q = d3 - 4.f * d1;
