@@ -101,3 +101,48 @@ extern "C" int st3d_comm_destroy(st3d_comm *comm) {
     delete comm;
     return ST3D_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// roctx ranges (the reference has no tracing; its tqdm bars become named ranges a profiler can show).
+// The roctx library is bound at run time like RCCL, and only when ST3D_ROCTX=1: without it both calls return at once.
+namespace {
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    bool tried = false;
+};
+Roctx &roctx() {
+    static Roctx r;
+    if (!r.tried) {
+        r.tried = true;
+        const char *e = getenv("ST3D_ROCTX");
+        if (e && e[0] == '1') {
+            // (rocprofv3 listens to the rocprofiler-sdk flavour of roctx; libroctx64 is the roctracer one)
+            for (const char *name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "/opt/rocm/lib/librocprofiler-sdk-roctx.so",
+                                     "libroctx64.so", "libroctx64.so.4", "/opt/rocm/lib/libroctx64.so"}) {
+                if (void *lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+                    r.push = reinterpret_cast<int (*)(const char *)>(dlsym(lib, "roctxRangePushA"));
+                    r.pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+                    if (r.push && r.pop) break;
+                    r.push = nullptr; r.pop = nullptr;
+                }
+            }
+        }
+    }
+    return r;
+}
+}  // namespace
+
+extern "C" int st3d_trace_push(const char *name) {
+    Roctx &r = roctx();
+    if (r.push && name) r.push(name);
+    return ST3D_OK;
+}
+
+extern "C" int st3d_trace_pop(void) {
+    Roctx &r = roctx();
+    if (r.pop) r.pop();
+    return ST3D_OK;
+}
+
+extern "C" int st3d_trace_enabled(void) { return roctx().push ? 1 : 0; }

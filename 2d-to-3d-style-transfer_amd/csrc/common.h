@@ -13,6 +13,14 @@ void set_error(const char *fmt, ...);
 
 inline hipStream_t as_stream(st3d_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// roctx range for rocprofv3 --marker-trace (st3d_trace_push / st3d_trace_pop, comm.hip): no-ops unless ST3D_ROCTX=1
+struct TraceRange {
+    explicit TraceRange(const char *name) { st3d_trace_push(name); }
+    ~TraceRange() { st3d_trace_pop(); }
+    TraceRange(const TraceRange &) = delete;
+    TraceRange &operator=(const TraceRange &) = delete;
+};
+
 #define ST3D_CHECK_ARG(cond)                                                             \
     do {                                                                                 \
         if (!(cond)) {                                                                   \

@@ -440,6 +440,7 @@ extern "C" size_t st3d_plan_bytes(const st3d_plan *p) { return p ? p->bytes : 0;
 extern "C" int st3d_plan_forward(st3d_plan *p, const float *imgs, int n, int upto_module, st3d_stream_t stream) {
     ST3D_CHECK_ARG(p && imgs);
     ST3D_CHECK_ARG(n > 0 && n <= p->B && upto_module >= 0 && upto_module < kModules);
+    st3d::TraceRange tr("vgg_forward");
     return forward(p, imgs, n, upto_module, true, st3d::as_stream(stream));
 }
 
@@ -572,7 +573,11 @@ extern "C" int st3d_plan_loss(st3d_plan *p, const float *current, int n, int bat
 
 static int plan_loss_enqueue(st3d_plan *p, const float *current, int n, int batch_denom, float style_weight,
                              float content_weight, float *loss_out, float *grad_current, hipStream_t s) {
-    ST3D_TRY(forward(p, current, n, 28, false, s));
+    {
+        st3d::TraceRange tr("vgg_forward");
+        ST3D_TRY(forward(p, current, n, 28, false, s));
+    }
+    st3d::TraceRange tr_loss("gram_and_losses");
 
     const double bd = (double)batch_denom;
     // content loss: mean over (B,C,H,W) of (F - Ft)^2            (losses.py:31)
@@ -602,6 +607,8 @@ static int plan_loss_enqueue(st3d_plan *p, const float *current, int n, int batc
         ST3D_TRY(st3d_sqdiff_sum_multi(items, 6, p->partials, loss_out, 1, 1, style_weight, content_weight, s));
     }
     if (!grad_current) return ST3D_OK;
+    st3d_trace_pop();                                  // (gram_and_losses ends here; its guard pops "vgg_backward" below)
+    st3d_trace_push("vgg_backward");
 
     // ---- backward: gradient w.r.t. the post-ReLU output of each conv, top down
     float *g = p->gbuf[0], *gn = p->gbuf[1];
@@ -679,6 +686,7 @@ extern "C" int st3d_plan_backward(st3d_plan *p, int n, int upto_module, const fl
                                   st3d_stream_t stream) {
     ST3D_CHECK_ARG(p && grad_modules && grad_image);
     ST3D_CHECK_ARG(n > 0 && n <= p->B && n == p->last_n && upto_module >= 0 && upto_module < kModules);
+    st3d::TraceRange tr("vgg_backward");
     hipStream_t s = st3d::as_stream(stream);
     float *g = p->gbuf[0], *gn = p->gbuf[1];
     bool have_g = false, g_is_pooled = false;

@@ -123,6 +123,9 @@ SIGNATURES = {
     "st3d_comm_init": (c_int, [ctypes.POINTER(ctypes.c_void_p), c_int, c_int, ctypes.c_char_p]),
     "st3d_allreduce_sum_f32": (c_int, [ctypes.c_void_p, c_f32p, c_size, c_stream]),
     "st3d_comm_destroy": (c_int, [ctypes.c_void_p]),
+    "st3d_trace_push": (c_int, [ctypes.c_char_p]),
+    "st3d_trace_pop": (c_int, []),
+    "st3d_trace_enabled": (c_int, []),
     "st3d_plan_profile": (c_int, [ctypes.c_void_p, c_int]),
     "st3d_plan_profile_read": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_float), ctypes.POINTER(c_int)]),
     "st3d_plan_profile_launches": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_float), c_int,

@@ -545,3 +545,26 @@ def device_info(device=0):
     name = ctypes.create_string_buffer(128)
     call("st3d_device_info", device, ctypes.byref(cu), ctypes.byref(hbm), name, 128)
     return {"cu_count": cu.value, "hbm_bytes": hbm.value, "name": name.value.decode()}
+
+
+
+# ---------------------------------------------------------------------------- roctx ranges (ST3D_ROCTX=1; include/st3d.h)
+class trace:
+    """with ops.trace("render"): ...  -- a named range for rocprofv3 --marker-trace around a host phase of the step (the
+    library marks the VGG phases itself).  Costs nothing unless ST3D_ROCTX=1 was set before the first call."""
+    _on = None
+
+    def __init__(self, name):
+        self.name = name.encode()
+
+    def __enter__(self):
+        if trace._on is None:
+            trace._on = os.environ.get("ST3D_ROCTX") == "1" and _lib.load().st3d_trace_enabled() == 1
+        if trace._on:
+            _lib.load().st3d_trace_push(self.name)
+        return self
+
+    def __exit__(self, *exc):
+        if trace._on:
+            _lib.load().st3d_trace_pop()
+        return False

@@ -146,18 +146,20 @@ class Adam:
 
     @torch.no_grad()
     def step(self):
-        grads = self._reduced_grads()
-        for group in self.param_groups:
-            for p in group["params"]:
-                g = grads.get(id(p))
-                if g is None:
-                    continue
-                st = self._state_of(p)
-                st["step"] += 1
-                if not p.is_contiguous():
-                    raise RuntimeError("st3d Adam needs contiguous parameters")
-                ops.adam_step(p.data, g, st["exp_avg"], st["exp_avg_sq"], st["step"], group["lr"], self.betas[0],
-                              self.betas[1], self.eps)
+        with ops.trace("allreduce"):
+            grads = self._reduced_grads()
+        with ops.trace("adam"):
+            for group in self.param_groups:
+                for p in group["params"]:
+                    g = grads.get(id(p))
+                    if g is None:
+                        continue
+                    st = self._state_of(p)
+                    st["step"] += 1
+                    if not p.is_contiguous():
+                        raise RuntimeError("st3d Adam needs contiguous parameters")
+                    ops.adam_step(p.data, g, st["exp_avg"], st["exp_avg_sq"], st["step"], group["lr"], self.betas[0],
+                                  self.betas[1], self.eps)
 
     def state_dict(self):
         """Positional (like torch.optim): entry k belongs to the k-th parameter in construction order."""

@@ -314,6 +314,11 @@ class _RenderFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_rgb, _grad_mask):
+        with ops.trace("render_backward"):
+            return _RenderFn._backward(ctx, grad_rgb, _grad_mask)
+
+    @staticmethod
+    def _backward(ctx, grad_rgb, _grad_mask):
         need_v, need_t = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         gtex = gverts = None
         if need_v or need_t:
@@ -359,6 +364,11 @@ class _SoftRenderFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_rgb, _grad_alpha):
+        with ops.trace("render_backward"):
+            return _SoftRenderFn._backward(ctx, grad_rgb, _grad_alpha)
+
+    @staticmethod
+    def _backward(ctx, grad_rgb, _grad_alpha):
         need_v, need_t = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         gtex = gverts = None
         if need_v or need_t:
@@ -411,6 +421,12 @@ def reaches_near_plane(verts, R, T, z_clip):
 
 
 def render_views(meshes, R, T, image_size, raster_settings=None, blend_params=None):
+    """``_render_views`` inside a named range (``ST3D_ROCTX=1``: rocprofv3 --marker-trace shows the step's phases)."""
+    with ops.trace("render"):
+        return _render_views(meshes, R, T, image_size, raster_settings, blend_params)
+
+
+def _render_views(meshes, R, T, image_size, raster_settings=None, blend_params=None):
     """All B views in one batch of launches -> (rgb (B,3,S,S), coverage (B,1,S,S)).  Coverage is the 0/1 mask under
     the reference's hard settings (whichever kernels render them) and softmax_rgb_blend's alpha under soft settings;
     both satisfy ``coverage > 0`` == covered."""

@@ -33,6 +33,7 @@
  *   ST3D_GRAM_BWD_MT, ST3D_GRAM_BWD_K64, ST3D_GRAM_BWD_SYM=0   Gram backward tile shapes / the general kernel
  *   ST3D_RASTER_BINS=0          flat face sweep instead of the coarse 64x64-pixel bins
  *   ST3D_POISON_PLAN=1          plan workspaces start as 0xFF (read-before-write detector of the tests)
+ *   ST3D_ROCTX=1                roctx ranges around the phases of a step (st3d_trace_push / st3d_trace_pop below)
  * Read by the Python host (st3d/): ST3D_DETERMINISTIC=0 (float-atomic scatters), ST3D_GRAPH=1 (HIP-graph replay of
  * the loss step), ST3D_NEAR_PLANE=raise, ST3D_MAX_PLANS, ST3D_VGG19_WEIGHTS, ST3D_DIST_BACKEND, ST3D_NCCL.
  * Lab builds only (ST3D_LAB=1 python build.py; never shipped): ST3D_WINO_VARIANT=8 (the retired 8-wave Winograd
@@ -444,6 +445,15 @@ int st3d_comm_unique_id(unsigned char id_out[ST3D_COMM_ID_BYTES]);
 int st3d_comm_init(st3d_comm **out, int rank, int world, const unsigned char unique_id[ST3D_COMM_ID_BYTES]);
 int st3d_allreduce_sum_f32(st3d_comm *comm, float *buf /* device, in place */, size_t n, st3d_stream_t stream);
 int st3d_comm_destroy(st3d_comm *comm);
+
+/* Named ranges for rocprofv3 --marker-trace (the reference's only progress reporting are tqdm bars,
+ * style_transfer.py:59, first_approach.py:191, second_approach.py:145).  With ST3D_ROCTX=1 in the environment the library
+ * binds libroctx64 at run time and st3d_plan_loss / st3d_plan_forward / st3d_plan_backward mark their phases (vgg_forward,
+ * gram_and_losses, vgg_backward); hosts bracket their own phases with push / pop (the Python host: render, render_backward,
+ * allreduce, adam).  Without it every call returns at once.  st3d_trace_enabled: 1 when ranges are being emitted. */
+int st3d_trace_push(const char *name);
+int st3d_trace_pop(void);
+int st3d_trace_enabled(void);
 
 #ifdef __cplusplus
 }

@@ -92,3 +92,20 @@ def test_winograd_shape_guards_are_pure_host_logic(lib_path):
     lib.st3d_wino43_packed_floats.restype = ctypes.c_size_t
     assert lib.st3d_wino43_packed_floats(512, 256) == 36 * 512 * 256
     assert lib.st3d_wino_supported(512, 512, 48, 48) == 1          # what the plan falls back to there
+
+
+def test_roctx_ranges_bind_only_on_request(lib_path):
+    """st3d_trace_push / st3d_trace_pop (SURVEY section 5) are no-ops unless ST3D_ROCTX=1, and then bind libroctx64 at run time;
+    balanced pushes and pops around nothing must not disturb anything (no GPU needed)."""
+    import subprocess
+    import sys
+    code = ("import ctypes, sys; l = ctypes.CDLL(%r); l.st3d_trace_push.argtypes = [ctypes.c_char_p];"
+            "l.st3d_trace_push(b'render'); l.st3d_trace_push(b'vgg_forward'); l.st3d_trace_pop(); l.st3d_trace_pop();"
+            "print(l.st3d_trace_enabled())") % lib_path
+    env = dict(os.environ)
+    env.pop("ST3D_ROCTX", None)
+    off = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert off.returncode == 0 and off.stdout.strip() == "0", off.stderr
+    env["ST3D_ROCTX"] = "1"
+    on = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert on.returncode == 0 and on.stdout.strip() == "1", on.stderr
