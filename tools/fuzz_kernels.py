@@ -59,6 +59,49 @@ def case_wino(rng, g):
     return ok1 and ok2 and ok3 and ok4 and ok5, f"wino N{N} {Cin}->{Cout} {H}x{W}: fwd {e1:.2e} dgrad {e2:.2e} chain {ok3} {ok4} {ok5}"
 
 
+def case_wino43(rng, g):
+    """F(4x4,3x3): random supported shape (both tile geometries), random persistent-slot count and slot numbering -- the
+    stream of stages crosses tile boundaries, ragged -- against fp64 and, bitwise, against its own separate-launch forms."""
+    Cin = int(rng.choice([64, 128, 192, 256, 320]))          # (the pack serves both directions: both channel counts % 64)
+    Cout = int(rng.choice([64, 128, 192]))
+    if rng.integers(0, 2):
+        H, W = 4 * int(rng.integers(1, 12)), 64 * int(rng.integers(1, 4))
+    else:
+        H, W = 8 * int(rng.integers(1, 6)), 32 * int(rng.integers(1, 6))
+    N = int(rng.integers(1, 4))
+    os.environ["ST3D_W43_SLOTS"] = str(int(rng.choice([0, 1, 2, 3, 4, 7, 16, 1000])))
+    os.environ["ST3D_W43_XCD"] = str(int(rng.integers(0, 2)))
+    if os.environ["ST3D_W43_SLOTS"] == "1000":
+        del os.environ["ST3D_W43_SLOTS"]
+    x = torch.randn(N, Cin, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5).double()
+    b = (torch.randn(Cout, generator=g) * 0.1).double()
+    pre = F.conv2d(x, w, b, padding=1)
+    uf, ud = ops.wino43_pack(w.float().to(dev))
+    xd = x.detach().float().to(dev)
+    yd = ops.wino43_fwd(xd, uf, b.float().to(dev), Cout, relu=True)
+    ok1, e1 = close(yd, F.relu(pre), 3e-5)
+    yf, pd, idx = ops.wino43_fwd(xd, uf, b.float().to(dev), Cout, relu=True, pool=True)
+    p2, idx2 = ops.maxpool2x2(yd)
+    ok2 = torch.equal(yf, yd) and torch.equal(pd, p2) and torch.equal(idx, idx2)
+    gy = torch.randn(pre.shape, generator=g, dtype=torch.float64)
+    gate = (yd.cpu() > 0).double()
+    gyg = (gy * gate).float().to(dev)
+    gx = ops.wino43_dgrad_chain(gyg, ud, Cin)
+    ok3, e3 = close(gx, torch.autograd.grad(pre, x, gy * gate)[0], 5e-5)
+    og = torch.randn(N, Cin, H, W, generator=g).to(dev)
+    ok4 = torch.equal(ops.wino43_dgrad_chain(gyg, ud, Cin, out_gate=og), torch.where(og > 0, gx, torch.zeros_like(gx)))
+    gp = torch.randn(N, Cout, H // 2, W // 2, generator=g).to(dev)
+    pidx = torch.randint(0, 4, (N, Cout, H // 2, W // 2), generator=g, dtype=torch.uint8).to(dev)
+    up = torch.zeros(N, Cout, H, W, device=dev)
+    for k in range(4):
+        up[:, :, (k >> 1)::2, (k & 1)::2] = gp * (pidx == k).float()
+    ok5 = torch.equal(ops.wino43_dgrad_chain(gp, ud, Cin, pool_idx=pidx), ops.wino43_dgrad_chain(up, ud, Cin))
+    tag = f"wino43 N{N} {Cin}->{Cout} {H}x{W} slots {os.environ.get('ST3D_W43_SLOTS', 'default')} xcd {os.environ['ST3D_W43_XCD']}"
+    os.environ.pop("ST3D_W43_SLOTS", None); os.environ.pop("ST3D_W43_XCD", None)
+    return ok1 and ok2 and ok3 and ok4 and ok5, f"{tag}: fwd {e1:.2e} pool {ok2} dgrad {e3:.2e} gate {ok4} unpool {ok5}"
+
+
 def case_gram(rng, g):
     C = 32 * int(rng.integers(1, 17))
     H, W = int(rng.integers(1, 70)), int(rng.integers(1, 70))
@@ -99,11 +142,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--only", default="", help="substring of the case names to run (e.g. wino43)")
     a = ap.parse_args()
     import numpy as np
     rng = np.random.default_rng(a.seed)
     g = torch.Generator().manual_seed(a.seed)
-    cases = [case_wino, case_gram, case_tap0]
+    cases = [case_wino, case_wino43, case_gram, case_tap0]
+    if a.only:
+        cases = [c for c in cases if a.only in c.__name__]
     t0, n, bad = time.time(), 0, 0
     while time.time() - t0 < a.seconds:
         fn = cases[n % len(cases)]
